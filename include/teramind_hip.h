@@ -1,0 +1,162 @@
+/* teramind_hip.h -- C ABI of libteramind_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (CTPLab/Tera-MIND) has no FFI / plugin interface for this path: its hot
+ * path is stock PyTorch modules.  This ABI is what a binding for the path would attach to;
+ * each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers owned by the caller (PyTorch-ROCm
+ *     allocations); the library borrows them for the duration of the enqueue and never
+ *     frees or allocates caller-visible memory.  The only library-owned device memory is
+ *     the packed weight arena (freed by tm_model_destroy).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden
+ *     device synchronisation, no internal threads.  One host thread per model.
+ *   - return value: 0 = OK, negative = TM_ERR_*; text via tm_last_error() (thread local).
+ *     No C++ exception crosses the ABI.
+ *   - image-like tensors are fp32, contiguous, NCHW as in the reference ("b (s z) h w").
+ */
+#ifndef TERAMIND_HIP_H
+#define TERAMIND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_ABI_VERSION 1
+
+enum {
+  TM_OK = 0,
+  TM_ERR_ARG = -1,        /* bad argument / unsupported configuration */
+  TM_ERR_STATE = -2,      /* call order violated (e.g. forward before finalize) */
+  TM_ERR_KEY = -3,        /* unknown / duplicate / missing state_dict key, or shape mismatch */
+  TM_ERR_HIP = -4,        /* a HIP runtime call failed */
+  TM_ERR_WORKSPACE = -5   /* workspace too small */
+};
+
+enum { TM_DTYPE_F32 = 0 };
+enum { TM_SAMPLE_DDPM = 0, TM_SAMPLE_DDIM = 1 };
+
+/* Model configuration.  Replaces BeatGANsUNetConfig as filled by
+ * TrainConfig.make_model_conf (config.py:280-326) from prep_config_parm (config_parm.py:5-59). */
+typedef struct tm_config {
+  int32_t patch_size;     /* image_size / patch_size: 64 */
+  int32_t rna_slc;        /* len(rna_tpl): 4   -> z_size = ceil(rna_slc/2) */
+  int32_t n_stain;        /* 2 for stain='all', else 1 */
+  int32_t rna_num;        /* 229 */
+  int32_t net_ch;         /* model_channels: 64 */
+  int32_t ch_mult[4];     /* (1,2,4,8) */
+  int32_t embed_ch;       /* embed_channels: 512 */
+  int32_t attn_res;       /* attention_resolutions[0]: 16 */
+  int32_t num_res_blocks; /* 2 */
+  int32_t vis_only;       /* 1: attention-map model (model/unet_attn.py), time_embed + rna_blocks[0] */
+  int32_t dtype;          /* TM_DTYPE_F32 */
+} tm_config;
+
+typedef struct tm_model tm_model;
+
+int tm_version(void);
+const char* tm_last_error(void);
+
+/* Replaces BeatGANsUNetConfig.make_model() (model/unet_ours.py:78-79,82-275). */
+int tm_model_create(const tm_config* cfg, tm_model** out);
+
+/* Replaces model.load_state_dict(state_dct, strict=True) (test_brn.py:140-147), one tensor
+ * at a time: `ref_key` is the reference state_dict key (after stripping 'model.'),
+ * `host_ptr` a contiguous fp32 HOST tensor of `shape[ndim]`. */
+int tm_model_load_param(tm_model* m, const char* ref_key, const void* host_ptr,
+                        const int64_t* shape, int ndim, int dtype);
+
+/* strict=True check (every key present), packs / pads / reorders into the device arena
+ * (replaces `.to(gpu_id)`, test_brn.py:148).  After this the weights are immutable. */
+int tm_model_finalize(tm_model* m);
+
+/* Number of keys the model expects / i-th key (for diagnostics and tests). */
+int tm_model_num_params(const tm_model* m);
+const char* tm_model_param_key(const tm_model* m, int i);
+
+/* Size of the arena in bytes (after finalize) and raw device pointer: lets the host
+ * broadcast rank 0's packed weights over RCCL instead of re-reading the checkpoint on
+ * every rank (replaces DDP's construction-time parameter broadcast, test_brn.py:149). */
+size_t tm_model_arena_bytes(const tm_model* m);
+void* tm_model_arena_ptr(tm_model* m);
+
+/* Workspace (activations, RNA pyramid, skips) needed by tm_unet_forward for
+ * `b` images of (p1-1)x(p2-1) interior patches, i.e. b*p1*p2 encoder patches. */
+size_t tm_workspace_bytes(const tm_model* m, int b, int p1, int p2, int want_pred2);
+
+/* Replaces BeatGANsUNetModel.forward (model/unet_ours.py:343-426) as called through
+ * _WrappedModel.forward (diffusion/diffusion.py:134-154):
+ *   x         [b*p1*p2, C, ps, ps] fp32        (C = n_stain*z_size)
+ *   t         [b] int64, ORIGINAL-scale timesteps (already mapped by timestep_map)
+ *   rna_dense [b*p1*p2, gn, gn, rna_slc*500] fp32 (dense, as test_brn.py:180-181 builds it)
+ *   p1, p2    patches per image side including the half-patch padding (= H/ps + 1)
+ *   pred      [b*(p1-1)*(p2-1), C, ps, ps]     collage ("o==0") decoder output
+ *   pred2     NULL, or [b*p1*p2, C, ps, ps]    original-patch ("o==1") decoder output
+ */
+int tm_unet_forward(tm_model* m, const void* x, const int64_t* t, const void* rna_dense,
+                    int b, int p1, int p2, void* pred, void* pred2_or_null,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-step scalar coefficients: the float64 tables of GaussianDiffusionBeatGans.__init__
+ * (diffusion/base.py:64-109) gathered at index i and cast `.float()` (base.py:643) by
+ * the host. */
+typedef struct tm_step_coefs {
+  float sqrt_recip_alphas_cumprod;     /* base.py:89  */
+  float sqrt_recipm1_alphas_cumprod;   /* base.py:90  */
+  float posterior_mean_coef1;          /* base.py:100 */
+  float posterior_mean_coef2;          /* base.py:103 */
+  float sigma;                         /* DDPM: exp(0.5*log_variance) (base.py:479-480), 0 when t==0 */
+  float sqrt_alpha_bar_prev;           /* DDIM: sqrt(alpha_bar_prev)      (base.py:492) */
+  float sqrt_one_minus_alpha_bar_prev; /* DDIM: sqrt(1 - alpha_bar_prev)  (base.py:493, eta=0) */
+} tm_step_coefs;
+
+/* Replaces p_mean_variance's eps re-tiling + x0 / clamp / posterior mean
+ * (diffusion/base.py:386-393,423-427), ddm_sample's DDPM / DDIM(eta=0) update (:476-498) and
+ * the un-patchify + crop of ddm_sample_loop_progressive (:627-628):
+ *   x_patches [b*(P1+1)*(P2+1), C, ps, ps]; eps [b*P1*P2, C, ps, ps] (model pred);
+ *   noise     NULL or like x_patches (DDPM);  x_prev_img [b, C, P1*ps, P2*ps]. */
+int tm_sampler_step(const tm_step_coefs* coefs, const void* x_patches, const void* eps,
+                    const void* noise_or_null, void* x_prev_img, int b, int P1, int P2, int C,
+                    int ps, int mode, void* stream);
+
+/* Replaces F.pad(img, halfp) + rearrange(im2tl) (diffusion/base.py:606-607):
+ *   img [b, C, P1*ps, P2*ps] -> patches [b*(P1+1)*(P2+1), C, ps, ps], zero border. */
+int tm_pad_patchify(const void* img, void* patches, int b, int C, int P1, int P2, int ps,
+                    float pad_value, void* stream);
+
+/* Replaces unet_attn.BeatGANsUNetModel.get_rna (model/unet_attn.py:143-173):
+ *   rna_dense [B, gn, gn, rna_slc*500] -> attn_out [4, B, G, G] fp32 softmax maps
+ *   (3 slice-pair-masked + 1 unmasked), rna_mid [B, G, rna_slc-2, gn, gn]. */
+size_t tm_gene_attn_workspace_bytes(const tm_model* m, int B);
+int tm_gene_attn(tm_model* m, const void* rna_dense, int B, void* attn_out, void* rna_mid,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+int tm_model_destroy(tm_model* m);
+
+/* ---- single-operator entry points (parity tests of the individual kernels) -------------
+ * Layout "CB8": fp32 [N][ceil(C/8)][Z][H][W][8] (channel blocks of 8, zero padded).      */
+
+/* NCDHW fp32 <-> CB8 */
+int tm_op_to_cb8(const void* x_ncdhw, void* y_cb8, int N, int C, int Z, int H, int W, void* stream);
+int tm_op_from_cb8(const void* x_cb8, void* y_ncdhw, int N, int C, int Z, int H, int W, void* stream);
+
+/* Conv3d k=3x3x3 pad 1 (Z must be 2) or k=1x1x1 on the MFMA implicit-GEMM kernel
+ * (replaces nn.Conv3d as used in ResBlock, model/MBAblocks.py:146-148,182-186,220-224).
+ *   w [Cout][Cin][k][k][k] HOST fp32, bias [Cout] HOST fp32; x, y CB8 DEVICE. */
+int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
+                    int N, int Cin, int Cout, int Z, int S, int ksize, int tile_variant,
+                    void* stream);
+
+/* Generic direct Conv3d (stem / head / RNA path), NCDHW in, NCDHW out. */
+int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N,
+                      int Cin, int Cout, int Zin, int S, int kz, int ky, int kx, int pz, int py,
+                      int px, int silu_in, int up2_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERAMIND_HIP_H */

@@ -1,0 +1,136 @@
+// Internal launcher interface between the executor (tm_model.hip) and the kernels
+// (tm_kernels.hip).  Not part of the public ABI (include/teramind_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tmk {
+
+// CB8 activation tensor view: fp32 [N][Cb][Z][H][W][8]; channel c lives in block c/8,
+// slot c%8; padded slots are kept at exactly 0.
+struct TV {
+  float* p = nullptr;
+  int N = 0, C = 0, Cb = 0, Z = 0, H = 0, W = 0;
+  long nstride = 0;                 // floats between consecutive n (>= Cb*Z*H*W*8)
+  long plane() const { return (long)Z * H * W * 8; }   // floats per channel block
+  // view of channel blocks [cb0, cb0+ncb) (C is set to ncb*8)
+  TV blocks(int cb0, int ncb) const {
+    TV v = *this;
+    v.p = p + (long)cb0 * plane();
+    v.Cb = ncb;
+    v.C = ncb * 8;
+    return v;
+  }
+};
+
+// ---- packed conv weights for the MFMA implicit-GEMM kernel ---------------------------
+// layout: [n_tile][cblk][tap][64 cout][8 cin] fp32, cout padded to a multiple of 64,
+// cin padded per concat segment to multiples of 8 ("virtual" cin order).
+struct ConvW {
+  const float* w = nullptr;     // device
+  const float* bias = nullptr;  // device, [ntile*64]
+  int Cout = 0, Cbi = 0, taps = 0, ntile = 0;
+};
+size_t conv_pack_floats(int Cout, int Cbi, int taps);
+// host-side packing; seg_c[i] = real channels of concat segment i (each padded to x8).
+void conv_pack_host(const float* w /*[Cout][Cin][taps]*/, int Cout, const int* seg_c, int nseg,
+                    int taps, float* out);
+void vec_pack_host(const float* v, const int* seg_c, int nseg, float* out);  // per-cin vector -> virtual order
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_UP2 = 2 };
+struct ConvLaunch {
+  TV x;                  // activated input, Cb == w.Cbi
+  ConvW w;
+  TV y;                  // output (for EPI_UP2: H,W = 2*x.H)
+  const TV* res = nullptr;   // optional residual (same geometry as y)
+  const TV* gate = nullptr;  // optional gate: y = res + gate * (conv + bias)
+  int flags = 0;
+  int tile_variant = 0;  // 0 auto, 1 = 128-voxel blocks, 2 = 256-voxel blocks
+};
+hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s);
+
+// ---- prep: concat + resample + RMSNorm(C) * w -> modulate -> act ---------------------
+struct PrepSrc {
+  const float* p = nullptr;
+  long nstride = 0;
+  int Cb = 0;
+  int collage = 0;
+};
+enum { RS_SAME = 0, RS_UP2 = 1, RS_DOWN2 = 2 };
+enum { MOD_NONE = 0, MOD_IMAGE = 1, MOD_VOXEL = 2 };
+struct PrepLaunch {
+  PrepSrc src[3];
+  int nsrc = 1;
+  int resample = RS_SAME;
+  int N = 0, Z = 0, S = 0;          // OUTPUT patches / plane size
+  int p1 = 0, p2 = 0;               // source patch grid per image (collage only)
+  const float* norm_w = nullptr;    // [Cbtot*8] virtual order, or null (no norm)
+  float inv_c = 0.f;                // 1 / real channel count
+  int mod = MOD_NONE;
+  const float* mod_scale = nullptr; // MOD_IMAGE: [b][..] row stride mod_stride; MOD_VOXEL: CB8 tensor
+  const float* mod_shift = nullptr;
+  long mod_stride = 0;              // MOD_IMAGE: floats per image row; MOD_VOXEL: nstride
+  int per_image = 1;                // output patches per image (n -> image index)
+  int act = 0;                      // 1 = SiLU
+  float* out = nullptr;
+  long out_nstride = 0;
+  float* raw = nullptr;             // optional un-normalised (resampled, concatenated) copy
+  long raw_nstride = 0;
+};
+hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
+
+// ---- generic direct conv (VALU) with strided accessors --------------------------------
+struct Acc5 {                        // address = n*sN + (c/8)*sCb + (c%8)*sC8 + z*sZ + y*sY + x*sX
+  long sN = 0, sCb = 0, sC8 = 0, sZ = 0, sY = 0, sX = 0;
+};
+Acc5 acc_ncdhw(int C, int Z, int H, int W);
+Acc5 acc_cb8(const TV& t);
+struct DirectLaunch {
+  const float* x = nullptr; Acc5 ax;
+  float* y = nullptr; Acc5 ay;
+  const float* w = nullptr;          // device [Cout][Cin][kz][ky][kx]
+  const float* bias = nullptr;       // device [Cout]
+  int N = 0, Cin = 0, Cout = 0;
+  int Zin = 0, Zout = 0, S = 0;      // in-plane size S x S (same in/out)
+  int kz = 1, ky = 1, kx = 1, pz = 0, py = 0, px = 0;
+  int silu_in = 0, up2_out = 0;
+};
+hipError_t launch_conv_direct(const DirectLaunch& L, hipStream_t s);
+
+// ---- layout converters ----------------------------------------------------------------
+hipError_t launch_to_cb8(const float* x, TV y, hipStream_t s);        // NCDHW -> CB8 (zero pads)
+hipError_t launch_from_cb8(TV x, float* y, hipStream_t s);            // CB8 -> NCDHW
+
+// ---- time embedding --------------------------------------------------------------------
+// te[b][E] = W2 * silu(W1 * sinusoid(t) + b1) + b2 ; then ss[b][tot] = Wall * silu(te) + ball
+hipError_t launch_time_embed(const int64_t* t, int b, int ch, int E, const float* w1,
+                             const float* b1, const float* w2, const float* b2, float* te,
+                             hipStream_t s);
+hipError_t launch_emb_all(const float* te, int b, int E, const float* wall, const float* ball,
+                          int tot, float* ss, hipStream_t s);
+
+// ---- gene-gene attention ---------------------------------------------------------------
+struct GeneW {       // all device pointers; matrices stored TRANSPOSED [in][out]
+  const float *wq_t, *bq, *wv_t, *bv, *qnorm, *wp_t, *bp, *norm2, *w1_t, *b1, *w2_t, *b2;
+};
+// rna dense [B][gn][gn][zs*500] -> tokens out [B][G][D] (D = zs*gn*gn, order z h w);
+// zmask_lo/hi: slices outside [lo,hi) are treated as zero (attention-map variants).
+hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, const GeneW& w,
+                            float* out_tok /*nullable*/, float* attn_map /*nullable [B][G][G]*/,
+                            int zmask_lo, int zmask_hi, hipStream_t s);
+hipError_t launch_rna_mid(const float* rna, int B, int gn, int zs, int G, float* out, hipStream_t s);
+
+// ---- windowed cross attention core -----------------------------------------------------
+// q, k, v: CB8 token tensors (tokens = voxels (z h w)); n_h x n_h windows over (H, W).
+hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float* qnorm_w,
+                              const float* knorm_w, TV o, hipStream_t s);
+
+// ---- sampler ---------------------------------------------------------------------------
+struct StepCoefs { float c_recip, c_recipm1, pm1, pm2, sigma, sab_prev, s1m_ab_prev; };
+hipError_t launch_sampler_step(const StepCoefs& c, const float* x_patches, const float* eps,
+                               const float* noise, float* out, int b, int P1, int P2, int C, int ps,
+                               int mode, hipStream_t s);
+hipError_t launch_pad_patchify(const float* img, float* patches, int b, int C, int P1, int P2,
+                               int ps, float pad, hipStream_t s);
+
+}  // namespace tmk

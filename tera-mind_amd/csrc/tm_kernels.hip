@@ -1,0 +1,1220 @@
+// Hand-written gfx950 (CDNA4) kernels of the Tera-MIND denoising hot path.
+//
+// Layout "CB8": fp32 [N][Cb][Z][H][W][8] -- channel blocks of 8 so that (a) an MFMA operand
+// fragment (8 channels of one voxel) is one 32-byte piece, (b) a row of voxels is contiguous
+// for coalesced HBM traffic, (c) a channel concat is a list of block ranges.
+//
+// Kernels (reference op each one replaces is cited at its definition):
+//   conv27_mfma / conv1_mfma   implicit-GEMM Conv3d on v_mfma_f32_32x32x2_f32 (exact fp32)
+//   prep_kernel                concat + collage/up/down gather + RMSNorm(C) + modulate + SiLU
+//   conv_direct_kernel         small convs (stem, head, RNA path) on VALU
+//   gene_attn_kernel           gene-gene attention block, one workgroup per patch
+//   window_attn_kernel         windowed gene-patch cross attention core
+//   time_embed / emb_all       timestep embedding MLP and all ResBlock emb_layers at once
+//   sampler_step / pad_patchify
+#include "tm_kernels.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace tmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TM_EPS 1e-6f
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float kBeta = 0.7978845608028654f;   // sqrt(2/pi)
+  const float kKappa = 0.044715f;
+  float inner = kBeta * (x + kKappa * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ==========================================================================================
+// Conv3d as implicit GEMM on the fp32 MFMA.
+//   D[cout 32][voxel 32] += W[cout 32][k 2] * X[k 2][voxel 32]   (v_mfma_f32_32x32x2_f32)
+// The weight is the A operand and the activation the B operand, so that each lane ends up
+// with 4 consecutive couts of ONE voxel per accumulator quad: the CB8 store is a coalesced
+// float4 per lane (32 voxels x 32 B contiguous per wave instruction).
+// One ds_read_b128 of 4 channels feeds 4 MFMAs: lanes 0-31 carry channels {0..3}, lanes
+// 32-63 channels {4..7} of the 8-channel block, identically for W and X, so MFMA #kk
+// contracts channels {kk, 4+kk}.
+//
+// Replaces nn.Conv3d(k=3, padding=1) of ResBlock (reference model/MBAblocks.py:146-148,
+// 182-186).  Z is 2 there, so for every output plane one of the three z taps only ever
+// multiplies zero padding: a workgroup owns ONE output plane zo and runs 18 of the 27 taps
+// (input planes zi = 0,1 with kz = zi + 1 - zo).
+// ==========================================================================================
+struct ConvArgs {
+  const float* x; long x_nstride; long x_plane;
+  const float* w; const float* bias;
+  float* y; long y_nstride; long y_plane; int Cob;
+  const float* res; long res_nstride;
+  const float* gate; long gate_nstride;
+  int N, S, Z, Cbi, ntile, flags;
+};
+
+template <int WM>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][WM], int nt, int h,
+                                              const int (&on)[WM], const int (&ooff)[WM], int S_out) {
+  // ooff: in-plane float offset of the voxel in the OUTPUT plane geometry (or -1)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cob = nt * 8 + ct * 4 + g;
+      if (cob >= a.Cob) continue;
+      const f32x4 bv = *(const f32x4*)(a.bias + (long)cob * 8 + 4 * h);
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) {
+        if (ooff[mt] < 0) continue;
+        f32x4 o;
+        o[0] = acc[ct][mt][4 * g + 0] + bv[0];
+        o[1] = acc[ct][mt][4 * g + 1] + bv[1];
+        o[2] = acc[ct][mt][4 * g + 2] + bv[2];
+        o[3] = acc[ct][mt][4 * g + 3] + bv[3];
+        if (a.flags & EPI_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_f(o[j]);
+        }
+        const long pl = (long)cob * a.y_plane + ooff[mt] + 4 * h;
+        if (a.gate) {
+          const f32x4 gv = *(const f32x4*)(a.gate + (long)on[mt] * a.gate_nstride + pl);
+          o *= gv;
+        }
+        if (a.res) {
+          const f32x4 rv = *(const f32x4*)(a.res + (long)on[mt] * a.res_nstride + pl);
+          o = rv + o;
+        }
+        float* yp = a.y + (long)on[mt] * a.y_nstride + pl;
+        if (a.flags & EPI_UP2) {
+          // nearest x2 on (H, W): ooff already addresses (2y, 2x) of the 2S plane
+          *(f32x4*)(yp) = o;
+          *(f32x4*)(yp + 8) = o;
+          *(f32x4*)(yp + (long)S_out * 8) = o;
+          *(f32x4*)(yp + (long)S_out * 8 + 8) = o;
+        } else {
+          *(f32x4*)(yp) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int TW>
+struct C27Geo {
+  static constexpr int MV = 4 * WM * 32;                 // voxels per workgroup
+  static constexpr int TR = (TW == 8) ? 8 : (MV / TW);   // tile rows
+  static constexpr int NPB = MV / (TR * TW);             // patches per workgroup
+  static constexpr int HR = TR + 2, HC = TW + 2;
+  static constexpr int XV = NPB * 2 * HR * HC;           // halo voxels (2 input planes)
+  static constexpr int XPIECES = XV * 2;                 // 16-byte pieces
+  static constexpr int PX = (XPIECES + 255) / 256;
+  static constexpr int WFLOATS = 18 * 64 * 8;
+  static constexpr int PW = WFLOATS / 4 / 256;           // = 9
+  static constexpr int LDS_FLOATS = WFLOATS + XV * 8;
+};
+
+template <int WM, int TW>
+__global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
+  using G = C27Geo<WM, TW>;
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+  float* lw = lds;
+  float* lx = lds + G::WFLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+
+  const int S = a.S;
+  const int tiles_c = S / TW, tiles_r = S / G::TR;
+  const int tiles = tiles_c * tiles_r;
+  const int bid = blockIdx.x;
+  const int nt = bid % a.ntile;
+  int mt_ = bid / a.ntile;
+  const int pg = mt_ / (2 * tiles);
+  mt_ -= pg * 2 * tiles;
+  const int zo = mt_ / tiles;
+  mt_ -= zo * tiles;
+  const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
+
+  // ---- per-thread staging descriptors (constant over the K loop) ----
+  long xoff[G::PX];
+#pragma unroll
+  for (int k = 0; k < G::PX; ++k) {
+    const int i = tid + k * 256;
+    long off = -1;
+    if (i < G::XPIECES) {
+      const int half = i & 1;
+      int v = i >> 1;
+      const int hc = v % G::HC; v /= G::HC;
+      const int hr = v % G::HR; v /= G::HR;
+      const int zi = v & 1;
+      const int ps = v >> 1;
+      const int n = pg * G::NPB + ps;
+      const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
+      if (n < a.N && y >= 0 && y < S && x >= 0 && x < S)
+        off = (long)n * a.x_nstride + ((long)(zi * S + y) * S + x) * 8 + half * 4;
+    }
+    xoff[k] = off;
+  }
+  // weights: taps [(1-zo)*9, (1-zo)*9+18) of this (n-tile, cblk) are contiguous
+  const float* wsrc = a.w + ((long)nt * a.Cbi * 27 + (1 - zo) * 9) * 512 + tid * 4;
+  const long w_cb_stride = 27 * 512;
+
+  // ---- per-lane fragment addresses ----
+  int xb[WM];
+  int on[WM], ooff[WM];
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt) {
+    const int v = (wv * WM + mt) * 32 + i32;
+    const int ps = v / (G::TR * TW);
+    const int rem = v - ps * (G::TR * TW);
+    const int r = rem / TW, c = rem - r * TW;
+    xb[mt] = ((ps * 2 * G::HR + r) * G::HC + c) * 8 + 4 * h;
+    const int n = pg * G::NPB + ps;
+    on[mt] = n;
+    const int y = tr * G::TR + r, x = tc * TW + c;
+    if (n < a.N) {
+      if (a.flags & EPI_UP2) ooff[mt] = ((zo * 2 * S + 2 * y) * 2 * S + 2 * x) * 8;
+      else ooff[mt] = ((zo * S + y) * S + x) * 8;
+    } else ooff[mt] = -1;
+  }
+  const int wb = i32 * 8 + 4 * h;
+
+  f32x16 acc[2][WM];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
+
+  f32x4 xr[G::PX], wr[G::PW];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_stage = [&](int cb) {
+    const float* xp = a.x + (long)cb * a.x_plane;
+#pragma unroll
+    for (int k = 0; k < G::PX; ++k) xr[k] = (xoff[k] >= 0) ? *(const f32x4*)(xp + xoff[k]) : zero4;
+    const float* wp = wsrc + (long)cb * w_cb_stride;
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) wr[k] = *(const f32x4*)(wp + k * 1024);
+  };
+
+  load_stage(0);
+  for (int cb = 0; cb < a.Cbi; ++cb) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < G::PX; ++k)
+      if (tid + k * 256 < G::XPIECES) *(f32x4*)(lx + (tid + k * 256) * 4) = xr[k];
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) *(f32x4*)(lw + (tid + k * 256) * 4) = wr[k];
+    __syncthreads();
+    if (cb + 1 < a.Cbi) load_stage(cb + 1);
+
+#pragma unroll
+    for (int zi = 0; zi < 2; ++zi) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = zi * 9 + ky * 3 + kx;
+          const int xd = ((zi * G::HR + ky) * G::HC + kx) * 8;
+          f32x4 wf[2], xf[WM];
+          wf[0] = *(const f32x4*)(lw + tap * 512 + wb);
+          wf[1] = *(const f32x4*)(lw + tap * 512 + 256 + wb);
+#pragma unroll
+          for (int mt = 0; mt < WM; ++mt) xf[mt] = *(const f32x4*)(lx + xb[mt] + xd);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int mt = 0; mt < WM; ++mt)
+                acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][kk], xf[mt][kk], acc[ct][mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  conv_epilogue<WM>(a, acc, nt, h, on, ooff, 2 * S);
+}
+
+// ---- 1x1x1 conv / Linear over voxels (flat voxel tiles, KC channel blocks per stage) ----
+// Replaces the skip_connection Conv3d(k=1) (model/MBAblocks.py:220-224) and every nn.Linear
+// of AttnBlock / Attention / Mlp applied to '(z h w) c' tokens (model/MBAblocks.py:465,
+// 538-544; timm Mlp fc1/fc2).
+template <int WM>
+__global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
+  constexpr int MV = 4 * WM * 32;
+  constexpr int KC = 4;
+  constexpr int XP = KC * MV * 2 / 256;       // x pieces per thread
+  constexpr int WP = KC * 64 * 2 / 256;       // = 2
+  __shared__ __attribute__((aligned(16))) float lds[KC * 512 + KC * MV * 8];
+  float* lw = lds;
+  float* lx = lds + KC * 512;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int nt = bid % a.ntile;
+  const int mtile = bid / a.ntile;
+  const long VPN = (long)a.Z * a.S * a.S;      // voxels per n
+  const long vtot = VPN * a.N;
+
+  long xoff[XP];
+  int xkc[XP];
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    const int i = tid + k * 256;
+    const int half = i & 1;
+    const int v = (i >> 1) % MV;
+    xkc[k] = (i >> 1) / MV;
+    const long vg = (long)mtile * MV + v;
+    long off = -1;
+    if (vg < vtot) {
+      const long n = vg / VPN;
+      off = n * a.x_nstride + (vg - n * VPN) * 8 + half * 4;
+    }
+    xoff[k] = off;
+  }
+  const float* wsrc = a.w + (long)nt * a.Cbi * 512 + tid * 4;
+
+  int xb[WM], on[WM], ooff[WM];
+#pragma unroll
+  for (int mt = 0; mt < WM; ++mt) {
+    const int v = (wv * WM + mt) * 32 + i32;
+    xb[mt] = v * 8 + 4 * h;
+    const long vg = (long)mtile * MV + v;
+    if (vg < vtot) {
+      const long n = vg / VPN;
+      on[mt] = (int)n;
+      ooff[mt] = (int)((vg - n * VPN) * 8);
+    } else { on[mt] = 0; ooff[mt] = -1; }
+  }
+  const int wb = i32 * 8 + 4 * h;
+
+  f32x16 acc[2][WM];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
+
+  f32x4 xr[XP], wr[WP];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_stage = [&](int cb0) {
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      const int cb = cb0 + xkc[k];
+      xr[k] = (xoff[k] >= 0 && cb < a.Cbi) ? *(const f32x4*)(a.x + (long)cb * a.x_plane + xoff[k]) : zero4;
+    }
+#pragma unroll
+    for (int k = 0; k < WP; ++k) {
+      const int i = tid + k * 256;             // piece index within [KC][64][2]
+      const int cb = cb0 + i / 128;
+      wr[k] = (cb < a.Cbi) ? *(const f32x4*)(wsrc + (long)cb0 * 512 + k * 1024) : zero4;
+    }
+  };
+
+  load_stage(0);
+  for (int cb0 = 0; cb0 < a.Cbi; cb0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XP; ++k) *(f32x4*)(lx + (tid + k * 256) * 4) = xr[k];
+#pragma unroll
+    for (int k = 0; k < WP; ++k) *(f32x4*)(lw + (tid + k * 256) * 4) = wr[k];
+    __syncthreads();
+    if (cb0 + KC < a.Cbi) load_stage(cb0 + KC);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      f32x4 wf[2], xf[WM];
+      wf[0] = *(const f32x4*)(lw + kc * 512 + wb);
+      wf[1] = *(const f32x4*)(lw + kc * 512 + 256 + wb);
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) xf[mt] = *(const f32x4*)(lx + kc * MV * 8 + xb[mt]);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < WM; ++mt)
+            acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][kk], xf[mt][kk], acc[ct][mt], 0, 0, 0);
+    }
+  }
+  conv_epilogue<WM>(a, acc, nt, h, on, ooff, 0);
+}
+
+size_t conv_pack_floats(int Cout, int Cbi, int taps) {
+  const int ntile = (Cout + 63) / 64;
+  return (size_t)ntile * Cbi * taps * 512;
+}
+
+void conv_pack_host(const float* w, int Cout, const int* seg_c, int nseg, int taps, float* out) {
+  int Cin = 0, Cbi = 0;
+  for (int s = 0; s < nseg; ++s) { Cin += seg_c[s]; Cbi += (seg_c[s] + 7) / 8; }
+  const int ntile = (Cout + 63) / 64;
+  memset(out, 0, conv_pack_floats(Cout, Cbi, taps) * sizeof(float));
+  int ci0 = 0, cb0 = 0;
+  for (int s = 0; s < nseg; ++s) {
+    for (int c = 0; c < seg_c[s]; ++c) {
+      const int ci = ci0 + c;
+      const int cb = cb0 + c / 8, c8 = c % 8;
+      for (int co = 0; co < Cout; ++co) {
+        const int nt = co / 64, col = co % 64;
+        const float* src = w + ((size_t)co * Cin + ci) * taps;
+        float* dst = out + (((size_t)nt * Cbi + cb) * taps) * 512 + (size_t)col * 8 + c8;
+        for (int t = 0; t < taps; ++t) dst[(size_t)t * 512] = src[t];
+      }
+    }
+    ci0 += seg_c[s];
+    cb0 += (seg_c[s] + 7) / 8;
+  }
+  (void)ntile;
+}
+
+void vec_pack_host(const float* v, const int* seg_c, int nseg, float* out) {
+  int ci0 = 0, cb0 = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const int nb = (seg_c[s] + 7) / 8;
+    for (int c = 0; c < nb * 8; ++c) out[cb0 * 8 + c] = (c < seg_c[s]) ? v[ci0 + c] : 0.f;
+    ci0 += seg_c[s];
+    cb0 += nb;
+  }
+}
+
+hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
+  ConvArgs a;
+  a.x = L.x.p; a.x_nstride = L.x.nstride; a.x_plane = L.x.plane();
+  a.w = L.w.w; a.bias = L.w.bias;
+  a.y = L.y.p; a.y_nstride = L.y.nstride; a.y_plane = L.y.plane(); a.Cob = L.y.Cb;
+  a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
+  a.gate = L.gate ? L.gate->p : nullptr; a.gate_nstride = L.gate ? L.gate->nstride : 0;
+  a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.w.Cbi; a.ntile = L.w.ntile; a.flags = L.flags;
+  if (L.x.Cb != L.w.Cbi || L.x.H != L.x.W) return hipErrorInvalidValue;
+  if (L.y.Cb > L.w.ntile * 8 || L.y.N != L.x.N) return hipErrorInvalidValue;
+  const long vox = (long)a.N * a.Z * a.S * a.S;
+  if (L.w.taps == 1) {
+    if (L.flags & EPI_UP2) return hipErrorInvalidValue;
+    if (L.y.H != L.x.H || L.y.Z != L.x.Z) return hipErrorInvalidValue;
+    int variant = L.tile_variant ? L.tile_variant : ((vox / 256) * a.ntile >= 512 ? 2 : 1);
+    if (variant == 2) {
+      const long mt = (vox + 255) / 256;
+      hipLaunchKernelGGL(conv1_mfma<2>, dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
+    } else {
+      const long mt = (vox + 127) / 128;
+      hipLaunchKernelGGL(conv1_mfma<1>, dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+  }
+  if (L.w.taps != 27 || a.Z != 2) return hipErrorInvalidValue;
+  const int S = a.S;
+  if (S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
+  if ((L.flags & EPI_UP2) ? (L.y.H != 2 * S) : (L.y.H != S)) return hipErrorInvalidValue;
+  int variant = L.tile_variant ? L.tile_variant : ((vox / 256) * a.ntile >= 512 ? 2 : 1);
+#define TM_LAUNCH27(WM, TW)                                                                     \
+  do {                                                                                          \
+    using G = C27Geo<WM, TW>;                                                                   \
+    const long tiles = (long)(S / TW) * (S / G::TR);                                            \
+    const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
+    const long grid = pgs * 2 * tiles * a.ntile;                                                \
+    hipLaunchKernelGGL((conv27_mfma<WM, TW>), dim3((unsigned)grid), dim3(256), 0, s, a);        \
+  } while (0)
+  if (variant == 2) {
+    if (S >= 32) TM_LAUNCH27(2, 32); else if (S == 16) TM_LAUNCH27(2, 16); else TM_LAUNCH27(2, 8);
+  } else {
+    if (S >= 32) TM_LAUNCH27(1, 32); else if (S == 16) TM_LAUNCH27(1, 16); else TM_LAUNCH27(1, 8);
+  }
+#undef TM_LAUNCH27
+  return hipGetLastError();
+}
+
+// ==========================================================================================
+// prep: gather (concat / collage / nearest-up / avg-down) + LlamaRMSNorm over C + modulate +
+// SiLU, written as the activated conv input.  Replaces th.cat + to_collage
+// (model/unet_ours.py:325-341,384,418), LlamaRMSNorm(dim=1) (model/MBAblocks.py:21-43), the
+// scale/shift of apply_conditions (:356-367), modulate (:608-614), nn.SiLU and
+// Upsample / Downsample (model/blocks.py:362-371,389-403) as they occur in ResBlock._forward
+// (:254-261) and AttnBlock._forward (:484-489).
+// 64 voxels per workgroup (lane = voxel: 2 KB contiguous per wave load), the 4 waves split
+// the channel blocks and combine their sums of squares through LDS.
+// ==========================================================================================
+struct PrepArgs { PrepLaunch L; };
+
+template <int NSUB>
+__global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
+  const PrepLaunch& L = pa.L;
+  __shared__ float red[4][NSUB][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int S = L.S, Z = L.Z;
+  const long vpn = (long)Z * S * S;
+  const long vidx = (long)blockIdx.x * 64 + lane;
+  const bool valid = vidx < vpn * L.N;
+  int n = 0, z = 0, y = 0, x = 0;
+  if (valid) {
+    n = (int)(vidx / vpn);
+    int rem = (int)(vidx - (long)n * vpn);
+    z = rem / (S * S); rem -= z * S * S;
+    y = rem / S; x = rem - y * S;
+  }
+  // source offsets
+  long soff[3][NSUB];
+  long splane[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k >= L.nsrc) { splane[k] = 0; continue; }
+    int Ss = S;
+    if (L.resample == RS_UP2) Ss = S / 2;
+    if (L.resample == RS_DOWN2) Ss = S * 2;
+    splane[k] = (long)Z * Ss * Ss * 8;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      int ns = n, ys = y, xs = x;
+      if (L.src[k].collage) {
+        const int q1 = L.p1 - 1, q2 = L.p2 - 1;
+        const int bi = n / (q1 * q2);
+        const int q = n - bi * q1 * q2;
+        int i = q / q2, j = q - i * q2;
+        ys = y + S / 2; if (ys >= S) { ys -= S; i += 1; }
+        xs = x + S / 2; if (xs >= S) { xs -= S; j += 1; }
+        ns = bi * L.p1 * L.p2 + i * L.p2 + j;
+      }
+      if (L.resample == RS_UP2) { ys = y >> 1; xs = x >> 1; }
+      if (L.resample == RS_DOWN2) { ys = 2 * y + (sub >> 1); xs = 2 * x + (sub & 1); }
+      soff[k][sub] = (long)ns * L.src[k].nstride + ((long)(z * Ss + ys) * Ss + xs) * 8;
+    }
+  }
+  float rstd[NSUB];
+#pragma unroll
+  for (int sub = 0; sub < NSUB; ++sub) rstd[sub] = 1.f;
+  if (L.norm_w) {
+    float ssq[NSUB];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) ssq[sub] = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= L.nsrc) continue;
+        for (int cb = wv; cb < L.src[k].Cb; cb += 4) {
+#pragma unroll
+          for (int sub = 0; sub < NSUB; ++sub) {
+            const float* p = L.src[k].p + soff[k][sub] + (long)cb * splane[k];
+            const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+            ssq[sub] += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] +
+                        a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) red[wv][sub][lane] = ssq[sub];
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      const float t = red[0][sub][lane] + red[1][sub][lane] + red[2][sub][lane] + red[3][sub][lane];
+      rstd[sub] = 1.0f / sqrtf(t * L.inv_c + TM_EPS);
+    }
+  }
+  if (!valid) return;
+  const long oplane = vpn * 8;
+  const long oin = ((long)(z * S + y) * S + x) * 8;
+  const int img = n / L.per_image;
+  int cbo = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k >= L.nsrc) continue;
+    for (int cb = wv; cb < L.src[k].Cb; cb += 4) {
+      const int cbv = cbo + cb;
+      float wn[8], sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { wn[j] = 1.f; sc[j] = 0.f; sh[j] = 0.f; }
+      if (L.norm_w) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wn[j] = L.norm_w[cbv * 8 + j];
+      }
+      if (L.mod == MOD_IMAGE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sc[j] = L.mod_scale[(long)img * L.mod_stride + cbv * 8 + j];
+          sh[j] = L.mod_shift[(long)img * L.mod_stride + cbv * 8 + j];
+        }
+      } else if (L.mod == MOD_VOXEL) {
+        const long mo = (long)n * L.mod_stride + (long)cbv * oplane + oin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = L.mod_scale[mo + j]; sh[j] = L.mod_shift[mo + j]; }
+      }
+      float o[8], r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[j] = 0.f; r[j] = 0.f; }
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const float* p = L.src[k].p + soff[k][sub] + (long)cb * splane[k];
+        const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+        const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = xv[j];
+          r[j] += v;
+          if (L.norm_w) v = wn[j] * (v * rstd[sub]);
+          if (L.mod != MOD_NONE) v = v * (1.0f + sc[j]) + sh[j];
+          if (L.act) v = silu_f(v);
+          o[j] += v;
+        }
+      }
+      if (NSUB == 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] *= 0.25f; r[j] *= 0.25f; }
+      }
+      float* op = L.out + (long)n * L.out_nstride + (long)cbv * oplane + oin;
+      *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
+      *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      if (L.raw) {
+        float* rp = L.raw + (long)n * L.raw_nstride + (long)cbv * oplane + oin;
+        *(f32x4*)rp = f32x4{r[0], r[1], r[2], r[3]};
+        *(f32x4*)(rp + 4) = f32x4{r[4], r[5], r[6], r[7]};
+      }
+    }
+    cbo += L.src[k].Cb;
+  }
+}
+
+hipError_t launch_prep(const PrepLaunch& L, hipStream_t s) {
+  PrepArgs pa; pa.L = L;
+  const long vox = (long)L.N * L.Z * L.S * L.S;
+  const unsigned grid = (unsigned)((vox + 63) / 64);
+  if (L.resample == RS_DOWN2) hipLaunchKernelGGL(prep_kernel<4>, dim3(grid), dim3(256), 0, s, pa);
+  else hipLaunchKernelGGL(prep_kernel<1>, dim3(grid), dim3(256), 0, s, pa);
+  return hipGetLastError();
+}
+
+// ==========================================================================================
+// Generic direct Conv3d on VALU (fp32 VALU rate == fp32 MFMA rate on gfx950, and these
+// layers are < 1 % of the FLOPs): stem Conv3d(2->64,(1,3,3)) (model/unet_ours.py:110-114),
+// head Conv3d(64->2,(1,3,3)) (:274-275), RNA pyramid SiLU->Conv3d(1,3,3)->Upsample
+// (:290-295) and down_z Conv3d(G->G,(ker,3,3),pad (0,1,1)) (model/MBAblocks.py:472-474).
+// lane = output voxel, blockIdx.y = block of 8 couts: weight reads are wave-uniform.
+// weights are pre-transposed to [tap][Cin][Cout_pad8].
+// ==========================================================================================
+struct DirectArgs { DirectLaunch L; int Cop; };
+
+__global__ __launch_bounds__(256) void conv_direct_kernel(DirectArgs da) {
+  const DirectLaunch& L = da.L;
+  const int S = L.S;
+  const long vpn = (long)L.Zout * S * S;
+  const long vidx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (vidx >= vpn * L.N) return;
+  const int n = (int)(vidx / vpn);
+  int rem = (int)(vidx - (long)n * vpn);
+  const int zo = rem / (S * S); rem -= zo * S * S;
+  const int y = rem / S, x = rem - y * S;
+  const int cob = blockIdx.y;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const float* xb = L.x + (long)n * L.ax.sN;
+  for (int kz = 0; kz < L.kz; ++kz) {
+    const int zi = zo + kz - L.pz;
+    if (zi < 0 || zi >= L.Zin) continue;
+    for (int ky = 0; ky < L.ky; ++ky) {
+      const int yi = y + ky - L.py;
+      for (int kx = 0; kx < L.kx; ++kx) {
+        const int xi = x + kx - L.px;
+        const bool ok = yi >= 0 && yi < S && xi >= 0 && xi < S;
+        const long base = zi * L.ax.sZ + (long)yi * L.ax.sY + (long)xi * L.ax.sX;
+        const int tap = (kz * L.ky + ky) * L.kx + kx;
+        const float* wt = L.w + ((long)tap * L.Cin) * da.Cop + cob * 8;
+        for (int ci = 0; ci < L.Cin; ++ci) {
+          float xv = 0.f;
+          if (ok) xv = xb[base + (long)(ci >> 3) * L.ax.sCb + (long)(ci & 7) * L.ax.sC8];
+          if (L.silu_in) xv = silu_f(xv);
+          const float* wp = wt + (long)ci * da.Cop;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(wp[j], xv, acc[j]);
+        }
+      }
+    }
+  }
+  float* yb = L.y + (long)n * L.ay.sN + (long)cob * L.ay.sCb;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int co = cob * 8 + j;
+    if (co >= L.Cout) break;
+    const float v = acc[j] + L.bias[co];
+    if (L.up2_out) {
+      const long o = zo * L.ay.sZ + (long)(2 * y) * L.ay.sY + (long)(2 * x) * L.ay.sX + (long)j * L.ay.sC8;
+      yb[o] = v; yb[o + L.ay.sX] = v; yb[o + L.ay.sY] = v; yb[o + L.ay.sY + L.ay.sX] = v;
+    } else {
+      yb[zo * L.ay.sZ + (long)y * L.ay.sY + (long)x * L.ay.sX + (long)j * L.ay.sC8] = v;
+    }
+  }
+}
+
+Acc5 acc_ncdhw(int C, int Z, int H, int W) {
+  Acc5 a;
+  a.sX = 1; a.sY = W; a.sZ = (long)H * W; a.sC8 = (long)Z * H * W; a.sCb = 8 * a.sC8;
+  a.sN = (long)C * Z * H * W;
+  return a;
+}
+Acc5 acc_cb8(const TV& t) {
+  Acc5 a;
+  a.sC8 = 1; a.sX = 8; a.sY = (long)t.W * 8; a.sZ = (long)t.H * t.W * 8; a.sCb = t.plane();
+  a.sN = t.nstride;
+  return a;
+}
+
+hipError_t launch_conv_direct(const DirectLaunch& L, hipStream_t s) {
+  DirectArgs da; da.L = L; da.Cop = (L.Cout + 7) / 8 * 8;
+  const long vox = (long)L.N * L.Zout * L.S * L.S;
+  dim3 grid((unsigned)((vox + 255) / 256), (unsigned)(da.Cop / 8));
+  hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, da);
+  return hipGetLastError();
+}
+
+// ==========================================================================================
+// layout converters
+// ==========================================================================================
+__global__ void to_cb8_kernel(const float* x, float* y, int N, int C, int Cb, long vpn, long y_nstride) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over N*Cb*vpn*8
+  const long tot = (long)N * Cb * vpn * 8;
+  if (i >= tot) return;
+  const int c8 = (int)(i & 7);
+  long r = i >> 3;
+  const long v = r % vpn; r /= vpn;
+  const int cb = (int)(r % Cb);
+  const int n = (int)(r / Cb);
+  const int c = cb * 8 + c8;
+  y[(long)n * y_nstride + ((long)cb * vpn + v) * 8 + c8] = (c < C) ? x[((long)n * C + c) * vpn + v] : 0.f;
+}
+__global__ void from_cb8_kernel(const float* x, float* y, int N, int C, long vpn, long x_nstride) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over N*C*vpn
+  const long tot = (long)N * C * vpn;
+  if (i >= tot) return;
+  const long v = i % vpn;
+  long r = i / vpn;
+  const int c = (int)(r % C);
+  const int n = (int)(r / C);
+  y[i] = x[(long)n * x_nstride + ((long)(c >> 3) * vpn + v) * 8 + (c & 7)];
+}
+hipError_t launch_to_cb8(const float* x, TV y, hipStream_t s) {
+  const long vpn = (long)y.Z * y.H * y.W;
+  const long tot = (long)y.N * y.Cb * vpn * 8;
+  hipLaunchKernelGGL(to_cb8_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, y.p, y.N, y.C, y.Cb, vpn, y.nstride);
+  return hipGetLastError();
+}
+hipError_t launch_from_cb8(TV x, float* y, hipStream_t s) {
+  const long vpn = (long)x.Z * x.H * x.W;
+  const long tot = (long)x.N * x.C * vpn;
+  hipLaunchKernelGGL(from_cb8_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x.p, y, x.N, x.C, vpn, x.nstride);
+  return hipGetLastError();
+}
+
+// ==========================================================================================
+// timestep embedding: sinusoid -> Linear -> SiLU -> Linear  (model/nn.py:187-206,
+// model/unet_ours.py:442-476), then every ResBlock's emb_layers = SiLU -> Linear(E, 2*Cout)
+// (model/MBAblocks.py:168-171) as ONE matrix [sum 2*Cout][E]: the value depends only on t,
+// so it is computed once per image instead of once per patch per block.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* t, int ch, int E, const float* w1,
+                                                         const float* b1, const float* w2, const float* b2,
+                                                         float* te) {
+  extern __shared__ float sm[];       // [ch] sinusoid, [E] hidden
+  float* sinu = sm;
+  float* hid = sm + ch;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float tv = (float)t[b];
+  const int half = ch / 2;
+  for (int i = tid; i < ch; i += 256) {
+    const int k = (i < half) ? i : i - half;
+    const float fr = expf(-logf(10000.0f) * (float)k / (float)half);
+    const float arg = tv * fr;
+    sinu[i] = (i < half) ? cosf(arg) : sinf(arg);
+  }
+  __syncthreads();
+  for (int o = tid; o < E; o += 256) {
+    float acc = b1[o];
+    for (int k = 0; k < ch; ++k) acc = fmaf(w1[(long)o * ch + k], sinu[k], acc);
+    hid[o] = silu_f(acc);
+  }
+  __syncthreads();
+  for (int o = tid; o < E; o += 256) {
+    float acc = b2[o];
+    for (int k = 0; k < E; ++k) acc = fmaf(w2[(long)o * E + k], hid[k], acc);
+    te[(long)b * E + o] = acc;
+  }
+}
+hipError_t launch_time_embed(const int64_t* t, int b, int ch, int E, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* te, hipStream_t s) {
+  hipLaunchKernelGGL(time_embed_kernel, dim3(b), dim3(256), (ch + E) * sizeof(float), s, t, ch, E, w1, b1, w2, b2, te);
+  return hipGetLastError();
+}
+
+// one wave per output row e; lanes split E; weight row kept in registers across images
+__global__ __launch_bounds__(256) void emb_all_kernel(const float* te, int b, int E, const float* wall,
+                                                      const float* ball, int tot, float* ss) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= tot) return;
+  float w[16];
+  const int per = E / 64;            // E <= 1024
+#pragma unroll
+  for (int j = 0; j < 16; ++j) w[j] = (j < per) ? wall[(long)e * E + j * 64 + lane] : 0.f;
+  const float bias = ball[e];
+  for (int i = 0; i < b; ++i) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < per) acc = fmaf(w[j], silu_f(te[(long)i * E + j * 64 + lane]), acc);
+    acc = wave_sum(acc);
+    if (lane == 0) ss[(long)i * tot + e] = acc + bias;
+  }
+}
+hipError_t launch_emb_all(const float* te, int b, int E, const float* wall, const float* ball, int tot,
+                          float* ss, hipStream_t s) {
+  if (E % 64 || E > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(emb_all_kernel, dim3((tot + 3) / 4), dim3(256), 0, s, te, b, E, wall, ball, tot, ss);
+  return hipGetLastError();
+}
+
+// ==========================================================================================
+// Gene-gene attention block (AttnBlock gene_trans=False: model/MBAblocks.py:492-501 and
+// Attention.forward :551-601 with k = q, q_norm on both, scale 1/64, no residuals), one
+// workgroup per patch, tokens = G genes x D = 64 features (z h w).  The softmax row lives
+// across the 64 lanes of a wave (4 keys per lane) and is reduced with wave shuffles.
+// P.V is computed as (P.tok).Wv^T + bv (rows of P sum to 1), so V is never materialised.
+// ==========================================================================================
+struct GeneArgs {
+  const float* rna; int B, gn, zs, G;
+  GeneW w;
+  float* out_tok; float* attn_map; float* scratch;
+  int zlo, zhi;
+};
+#define GENE_D 64
+#define GENE_QP 65      // padded row of the normalised-q image: conflict-free key reads
+
+__global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int G = a.G;
+  float* tok = sm;                       // [G][64]
+  float* qn = tok + G * GENE_D;          // [G][65]
+  float* prow = qn + G * GENE_QP;        // [4][Gp]
+  const int Gp = (G + 63) / 64 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = blockIdx.x;
+  const int gg = a.gn * a.gn;
+  const long rbase = (long)n * gg * a.zs * 500;
+  for (int i = tid; i < G * GENE_D; i += 256) {
+    const int d = i / G, g = i - d * G;
+    const int z = d / gg, hw = d - z * gg;
+    float v = 0.f;
+    if (z >= a.zlo && z < a.zhi) v = a.rna[rbase + ((long)hw * a.zs + z) * 500 + g];
+    tok[g * GENE_D + d] = v;
+  }
+  __syncthreads();
+  // ---- pass A: q = Linear(tok); qn = RMSNorm(q) * w ----
+  {
+    float wq[GENE_D];
+#pragma unroll
+    for (int k = 0; k < GENE_D; ++k) wq[k] = a.w.wq_t[k * GENE_D + lane];
+    const float bq = a.w.bq[lane], qw = a.w.qnorm[lane];
+    for (int g = wv; g < G; g += 4) {
+      float acc = bq;
+#pragma unroll
+      for (int k = 0; k < GENE_D; ++k) acc = fmaf(tok[g * GENE_D + k], wq[k], acc);
+      const float ss = wave_sum(acc * acc);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / GENE_D) + TM_EPS);
+      qn[g * GENE_QP + lane] = qw * (acc * rstd);
+    }
+  }
+  __syncthreads();
+  // ---- pass B: logits, softmax, P.tok, Wv, proj, norm2 ----
+  {
+    float wvv[GENE_D], wpp[GENE_D];
+    if (a.out_tok) {
+#pragma unroll
+      for (int k = 0; k < GENE_D; ++k) { wvv[k] = a.w.wv_t[k * GENE_D + lane]; wpp[k] = a.w.wp_t[k * GENE_D + lane]; }
+    }
+    float* pr = prow + wv * Gp;
+    for (int g = wv; g < G; g += 4) {
+      float lg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int d = 0; d < GENE_D; ++d) {
+        const float qv = qn[g * GENE_QP + d] * 0.125f;      // q * scale (MBAblocks.py:573)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int u = lane + 64 * j;
+          if (u < G) lg[j] = fmaf(qv, qn[u * GENE_QP + d], lg[j]);
+        }
+      }
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lg[j] *= 0.125f;                                    // SDPA's own 1/sqrt(64)
+        if (lane + 64 * j < G) m = fmaxf(m, lg[j]);
+      }
+      m = wave_max(m);
+      float ssum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lg[j] = (lane + 64 * j < G) ? expf(lg[j] - m) : 0.f;
+        ssum += lg[j];
+      }
+      ssum = wave_sum(ssum);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int u = lane + 64 * j;
+        const float p = lg[j] / ssum;
+        if (u < G) {
+          pr[u] = p;
+          if (a.attn_map) a.attn_map[((long)n * G + g) * G + u] = p;
+        }
+      }
+      if (!a.out_tok) continue;
+      __builtin_amdgcn_wave_barrier();
+      float pt = 0.f;
+      for (int u = 0; u < G; ++u) pt = fmaf(pr[u], tok[u * GENE_D + lane], pt);
+      float ov = a.w.bv[lane];
+#pragma unroll
+      for (int k = 0; k < GENE_D; ++k) ov = fmaf(__shfl(pt, k, 64), wvv[k], ov);
+      float op = a.w.bp[lane];
+#pragma unroll
+      for (int k = 0; k < GENE_D; ++k) op = fmaf(__shfl(ov, k, 64), wpp[k], op);
+      const float ss = wave_sum(op * op);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / GENE_D) + TM_EPS);
+      a.scratch[((long)n * G + g) * GENE_D + lane] = a.w.norm2[lane] * (op * rstd);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (!a.out_tok) return;
+  __syncthreads();
+  // ---- pass C: MLP 64 -> 256 (tanh-GELU) -> 64, weights staged in the freed LDS ----
+  float* w1 = sm;                  // [64][256]
+  float* w2 = sm + 64 * 256;       // [256][64]
+  for (int i = tid; i < 64 * 256; i += 256) { w1[i] = a.w.w1_t[i]; w2[i] = a.w.w2_t[i]; }
+  __syncthreads();
+  for (int g = wv; g < G; g += 4) {
+    const float hv = a.scratch[((long)n * G + g) * GENE_D + lane];
+    float y1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y1[j] = a.w.b1[lane + 64 * j];
+#pragma unroll
+    for (int k = 0; k < GENE_D; ++k) {
+      const float hk = __shfl(hv, k, 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y1[j] = fmaf(hk, w1[k * 256 + lane + 64 * j], y1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y1[j] = gelu_tanh_f(y1[j]);
+    float y2 = a.w.b2[lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 64; ++k) y2 = fmaf(__shfl(y1[j], k, 64), w2[(k + 64 * j) * 64 + lane], y2);
+    a.out_tok[((long)n * G + g) * GENE_D + lane] = y2;
+  }
+}
+
+static size_t gene_lds_bytes(int G) {
+  const int Gp = (G + 63) / 64 * 64;
+  size_t a = ((size_t)G * GENE_D + (size_t)G * GENE_QP + 4 * Gp) * sizeof(float);
+  size_t b = (size_t)2 * 64 * 256 * sizeof(float);
+  return a > b ? a : b;
+}
+
+hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, const GeneW& w, float* out_tok,
+                            float* attn_map, int zlo, int zhi, hipStream_t s) {
+  if (gn * gn * zs != GENE_D || G > 256) return hipErrorInvalidValue;
+  GeneArgs a;
+  a.rna = rna; a.B = B; a.gn = gn; a.zs = zs; a.G = G; a.w = w;
+  a.out_tok = out_tok; a.attn_map = attn_map; a.scratch = out_tok;   // norm2 output staged in-place
+  a.zlo = zlo; a.zhi = zhi;
+  const size_t lds = gene_lds_bytes(G);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gene_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gene_attn_kernel, dim3(B), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// rna_h[:, :, 1:-1] of the attention-map model (model/unet_attn.py:173): [B][G][zs-2][gn][gn]
+__global__ void rna_mid_kernel(const float* rna, int B, int gn, int zs, int G, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int gg = gn * gn, zm = zs - 2;
+  const long tot = (long)B * G * zm * gg;
+  if (i >= tot) return;
+  const int hw = (int)(i % gg);
+  long r = i / gg;
+  const int z = (int)(r % zm); r /= zm;
+  const int g = (int)(r % G);
+  const int n = (int)(r / G);
+  out[i] = rna[(long)n * gg * zs * 500 + ((long)hw * zs + (z + 1)) * 500 + g];
+}
+hipError_t launch_rna_mid(const float* rna, int B, int gn, int zs, int G, float* out, hipStream_t s) {
+  const long tot = (long)B * G * (zs - 2) * gn * gn;
+  if (tot <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rna_mid_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rna, B, gn, zs, G, out);
+  return hipGetLastError();
+}
+
+// ==========================================================================================
+// Windowed gene-patch cross attention core (Attention.forward with n_h=2, one head:
+// model/MBAblocks.py:555-595): per (patch, window) RMSNorm(q), RMSNorm(k) over C,
+// softmax(q.k^T / C) . v.  One workgroup per (patch, window); T = tokens per window.
+// ==========================================================================================
+struct WinArgs {
+  const float *q, *k, *v; long q_ns, k_ns, v_ns;
+  const float *qw, *kw;
+  float* o; long o_ns;
+  int C, Z, S;
+  long plane;
+};
+
+template <int T>
+__global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
+  constexpr int TT = T / 16;
+  constexpr int KC = 16;
+  constexpr int PS = T + 4;          // Pt row stride
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  int* tokoff = (int*)sm;            // [T]
+  float* rq = sm + T;                // [T]
+  float* rk = rq + T;                // [T]
+  float* qs = rk + T;                // [KC][T]
+  float* ks = qs + KC * T;           // [KC][T]
+  float* Pt = ks + KC * T;           // [T][PS]   Pt[u][t]
+  float* vs = Pt + T * PS;           // [16][128]
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x >> 2, win = blockIdx.x & 3;
+  const int wy = win >> 1, wx = win & 1;
+  const int S = a.S, hs = S / 2, C = a.C;
+  for (int t = tid; t < T; t += 256) {
+    const int z = t / (hs * hs);
+    const int r = t - z * hs * hs;
+    const int yl = r / hs, xl = r - yl * hs;
+    tokoff[t] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  __syncthreads();
+  const float* qb = a.q + (long)n * a.q_ns;
+  const float* kb = a.k + (long)n * a.k_ns;
+  const float* vb = a.v + (long)n * a.v_ns;
+  if (tid < 2 * T) {
+    const bool isq = tid < T;
+    const int t = isq ? tid : tid - T;
+    const float* p = (isq ? qb : kb) + tokoff[t];
+    float ss = 0.f;
+    for (int cb = 0; cb < C / 8; ++cb) {
+      const f32x4 a0 = *(const f32x4*)(p + (long)cb * a.plane), a1 = *(const f32x4*)(p + (long)cb * a.plane + 4);
+      ss += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] + a1[0] * a1[0] + a1[1] * a1[1] +
+            a1[2] * a1[2] + a1[3] * a1[3];
+    }
+    const float r = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+    if (isq) rq[t] = r; else rk[t] = r;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float acc[TT][TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[i][j] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += KC) {
+    // stage: items = (q|k, token, cblk of 2)
+    for (int it = tid; it < 2 * T * 2; it += 256) {
+      const int cbi = it & 1;
+      const int t = (it >> 1) % T;
+      const bool isq = (it >> 1) < T;
+      const int cb = c0 / 8 + cbi;
+      const float* p = (isq ? qb : kb) + tokoff[t] + (long)cb * a.plane;
+      const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+      const float r = isq ? rq[t] : rk[t];
+      const float* nw = (isq ? a.qw : a.kw) + cb * 8;
+      float* dst = (isq ? qs : ks) + (cbi * 8) * T + t;
+      dst[0 * T] = nw[0] * (a0[0] * r); dst[1 * T] = nw[1] * (a0[1] * r);
+      dst[2 * T] = nw[2] * (a0[2] * r); dst[3 * T] = nw[3] * (a0[3] * r);
+      dst[4 * T] = nw[4] * (a1[0] * r); dst[5 * T] = nw[5] * (a1[1] * r);
+      dst[6 * T] = nw[6] * (a1[2] * r); dst[7 * T] = nw[7] * (a1[3] * r);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      float av[TT], bv[TT];
+#pragma unroll
+      for (int i = 0; i < TT; ++i) av[i] = qs[kc * T + ty * TT + i];
+#pragma unroll
+      for (int j = 0; j < TT; ++j) bv[j] = ks[kc * T + tx * TT + j];
+#pragma unroll
+      for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const float inv_c = 1.0f / (float)C;        // (q*scale) . k * scale, scale = C^-1/2
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+#pragma unroll
+    for (int j = 0; j < TT; ++j) Pt[(tx * TT + j) * PS + ty * TT + i] = acc[i][j] * inv_c;
+  __syncthreads();
+  if (tid < T) {
+    float m = -INFINITY;
+    for (int u = 0; u < T; ++u) m = fmaxf(m, Pt[u * PS + tid]);
+    float ssum = 0.f;
+    for (int u = 0; u < T; ++u) { const float e = expf(Pt[u * PS + tid] - m); Pt[u * PS + tid] = e; ssum += e; }
+    for (int u = 0; u < T; ++u) Pt[u * PS + tid] = Pt[u * PS + tid] / ssum;
+  }
+  __syncthreads();
+  float* ob = a.o + (long)n * a.o_ns;
+  for (int c0 = 0; c0 < C; c0 += 128) {
+    float oa[TT][8];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) oa[i][j] = 0.f;
+    for (int u0 = 0; u0 < T; u0 += 16) {
+      {
+        const int uu = tid >> 4, cbi = tid & 15;
+        const float* p = vb + tokoff[u0 + uu] + (long)(c0 / 8 + cbi) * a.plane;
+        *(f32x4*)(vs + uu * 128 + cbi * 8) = *(const f32x4*)p;
+        *(f32x4*)(vs + uu * 128 + cbi * 8 + 4) = *(const f32x4*)(p + 4);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int uu = 0; uu < 16; ++uu) {
+        float pv[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) pv[i] = Pt[(u0 + uu) * PS + ty * TT + i];
+        const f32x4 v0 = *(const f32x4*)(vs + uu * 128 + tx * 8), v1 = *(const f32x4*)(vs + uu * 128 + tx * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+          oa[i][0] = fmaf(pv[i], v0[0], oa[i][0]); oa[i][1] = fmaf(pv[i], v0[1], oa[i][1]);
+          oa[i][2] = fmaf(pv[i], v0[2], oa[i][2]); oa[i][3] = fmaf(pv[i], v0[3], oa[i][3]);
+          oa[i][4] = fmaf(pv[i], v1[0], oa[i][4]); oa[i][5] = fmaf(pv[i], v1[1], oa[i][5]);
+          oa[i][6] = fmaf(pv[i], v1[2], oa[i][6]); oa[i][7] = fmaf(pv[i], v1[3], oa[i][7]);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      float* p = ob + tokoff[ty * TT + i] + (long)(c0 / 8 + tx) * a.plane;
+      *(f32x4*)p = f32x4{oa[i][0], oa[i][1], oa[i][2], oa[i][3]};
+      *(f32x4*)(p + 4) = f32x4{oa[i][4], oa[i][5], oa[i][6], oa[i][7]};
+    }
+  }
+}
+
+template <int T>
+static hipError_t launch_win(const WinArgs& a, int N, hipStream_t s) {
+  const size_t lds = ((size_t)3 * T + 2 * 16 * T + (size_t)T * (T + 4) + 16 * 128) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)window_attn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(window_attn_kernel<T>, dim3(N * 4), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float* qnorm_w, const float* knorm_w,
+                              TV o, hipStream_t s) {
+  WinArgs a;
+  a.q = q.p; a.k = k.p; a.v = v.p; a.q_ns = q.nstride; a.k_ns = k.nstride; a.v_ns = v.nstride;
+  a.qw = qnorm_w; a.kw = knorm_w; a.o = o.p; a.o_ns = o.nstride;
+  a.C = q.Cb * 8; a.Z = q.Z; a.S = q.H; a.plane = q.plane();
+  if (a.C % 128 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
+  const int T = q.Z * (q.H / 2) * (q.H / 2);
+  if (T == 128) return launch_win<128>(a, q.N, s);
+  if (T == 32) return launch_win<32>(a, q.N, s);
+  return hipErrorInvalidValue;
+}
+
+// ==========================================================================================
+// sampler step on interior pixels only (the -1 padded border of the eps re-tiling is cropped
+// away by the reference, base.py:389,628).  Compiled without fp contraction so that each
+// product and sum rounds exactly like the reference's separate torch ops.
+// ==========================================================================================
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void sampler_step_kernel(StepCoefs c, const float* xp, const float* eps,
+                                                           const float* noise, float* out, int b, int P1, int P2,
+                                                           int C, int ps, int mode) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = P1 * ps, W = P2 * ps, hp = ps / 2;
+  const long tot = (long)b * C * H * W;
+  if (i >= tot) return;
+  const int X = (int)(i % W);
+  long r = i / W;
+  const int Y = (int)(r % H); r /= H;
+  const int ch = (int)(r % C);
+  const int bi = (int)(r / C);
+  // padded-grid patch holding this pixel
+  const int Yp = Y + hp, Xp = X + hp;
+  const int pi = Yp / ps, pj = Xp / ps;
+  const long xo = ((((long)bi * (P1 + 1) + pi) * (P2 + 1) + pj) * C + ch) * ps * ps + (long)(Yp - pi * ps) * ps + (Xp - pj * ps);
+  const int ei = Y / ps, ej = X / ps;
+  const long eo = ((((long)bi * P1 + ei) * P2 + ej) * C + ch) * ps * ps + (long)(Y - ei * ps) * ps + (X - ej * ps);
+  const float xv = xp[xo], ev = eps[eo];
+  float x0 = c.c_recip * xv - c.c_recipm1 * ev;
+  x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+  float o;
+  if (mode == 0) {
+    const float mean = c.pm1 * x0 + c.pm2 * xv;
+    o = mean;
+    if (noise) o = mean + c.sigma * noise[xo];
+  } else {
+    const float e2 = (c.c_recip * xv - x0) / c.c_recipm1;
+    o = x0 * c.sab_prev + c.s1m_ab_prev * e2;
+  }
+  out[i] = o;
+}
+#pragma clang fp contract(fast)
+
+hipError_t launch_sampler_step(const StepCoefs& c, const float* x_patches, const float* eps, const float* noise,
+                               float* out, int b, int P1, int P2, int C, int ps, int mode, hipStream_t s) {
+  const long tot = (long)b * C * P1 * ps * P2 * ps;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, c, x_patches, eps,
+                     noise, out, b, P1, P2, C, ps, mode);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pad_patchify_kernel(const float* img, float* pt, int b, int C, int P1, int P2,
+                                                           int ps, float pad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = (long)b * (P1 + 1) * (P2 + 1) * C * ps * ps;
+  if (i >= tot) return;
+  const int x = (int)(i % ps);
+  long r = i / ps;
+  const int y = (int)(r % ps); r /= ps;
+  const int ch = (int)(r % C); r /= C;
+  const int pj = (int)(r % (P2 + 1)); r /= (P2 + 1);
+  const int pi = (int)(r % (P1 + 1));
+  const int bi = (int)(r / (P1 + 1));
+  const int hp = ps / 2;
+  const int Y = pi * ps + y - hp, X = pj * ps + x - hp;
+  float v = pad;
+  if (Y >= 0 && Y < P1 * ps && X >= 0 && X < P2 * ps) v = img[(((long)bi * C + ch) * P1 * ps + Y) * P2 * ps + X];
+  pt[i] = v;
+}
+hipError_t launch_pad_patchify(const float* img, float* patches, int b, int C, int P1, int P2, int ps, float pad,
+                               hipStream_t s) {
+  const long tot = (long)b * (P1 + 1) * (P2 + 1) * C * ps * ps;
+  hipLaunchKernelGGL(pad_patchify_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, img, patches, b, C,
+                     P1, P2, ps, pad);
+  return hipGetLastError();
+}
+
+}  // namespace tmk

@@ -1,0 +1,893 @@
+// C-ABI (include/teramind_hip.h) + host-side executor of the UNet / sampler / gene-attention
+// path.  The layer graph is the reference's `ours` model (model/unet_ours.py:82-426),
+// re-scheduled for inference: time embedding and every ResBlock's emb_layers computed once
+// per image, concat / collage / resample never materialised on their own (they are gather
+// rules of the prep kernel), skip tensors never cloned, `o == 1` decoder pass optional.
+#include "../../include/teramind_hip.h"
+#include "tm_kernels.h"
+
+#include <map>
+#include <string>
+#include <vector>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+using namespace tmk;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(TM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static const int RNA_TAIL[3] = {128, 64, 32};          // model/unet_ours.py:278-279
+
+// ------------------------------------------------------------------------------------------
+struct HostParam {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool loaded = false;
+};
+
+struct ResW {
+  std::string pfx;
+  std::vector<int> seg;       // real channels of each concat source
+  int cin = 0, cbi = 0, cout = 0;
+  bool has_skip = false;
+  ConvW c1, c2, skip;
+  const float* n1 = nullptr;  // [cbi*8] virtual order
+  const float* n2 = nullptr;  // [cout]
+  int emb_off = 0;
+};
+struct AttnW {
+  std::string pfx;
+  int C = 0, G = 0;
+  ConvW ada, q, kv, proj, fc1, fc2;
+  const float *n1 = nullptr, *n2 = nullptr, *qn = nullptr, *kn = nullptr;
+};
+struct DirectW {
+  const float* w = nullptr;   // [tap][Cin][Cop]
+  const float* bias = nullptr;
+  int Cin = 0, Cout = 0, kz = 1, ky = 1, kx = 1;
+};
+struct Op {           // one entry of a TimestepEmbedSequential
+  int kind;           // 0 res, 1 attn
+  int idx;            // index into res / attn
+  int mode;           // RS_*
+};
+struct EncEntry { int lvl; bool cat; std::vector<Op> ops; };
+struct DecEntry { int lvl; std::vector<Op> ops; };
+
+struct tm_model {
+  tm_config cfg;
+  int z = 0, gn = 0, D = 0, L = 4;
+  int rw[4];                          // rna pyramid widths
+  std::vector<std::pair<std::string, std::vector<int64_t>>> spec;
+  std::map<std::string, HostParam> host;
+  bool finalized = false;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  // graph
+  std::vector<ResW> res;
+  std::vector<AttnW> attn;
+  std::vector<EncEntry> enc;
+  std::vector<Op> mid;
+  std::vector<DecEntry> dec;
+  int emb_tot = 0;
+  // packed pointers
+  const float *te_w1 = nullptr, *te_b1 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
+  const float *emb_w = nullptr, *emb_b = nullptr;
+  GeneW gene;
+  DirectW downz, pyr[3], stem, head;
+  const float* out_norm = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------
+// graph + key enumeration (mirrors the constructor, model/unet_ours.py:134-296)
+// ------------------------------------------------------------------------------------------
+typedef std::vector<std::pair<std::string, std::vector<int64_t>>> Spec;
+static void K(Spec& s, const std::string& k, std::vector<int64_t> shp) { s.emplace_back(k, std::move(shp)); }
+
+static void spec_res(Spec& s, const std::string& p, int cin, int cout, int E) {
+  K(s, p + ".in_layers.0.weight", {1, cin, 1, 1});
+  K(s, p + ".in_layers.2.weight", {cout, cin, 3, 3, 3});
+  K(s, p + ".in_layers.2.bias", {cout});
+  K(s, p + ".emb_layers.1.weight", {2 * cout, E});
+  K(s, p + ".emb_layers.1.bias", {2 * cout});
+  K(s, p + ".out_layers.0.weight", {1, cout, 1, 1});
+  K(s, p + ".out_layers.3.weight", {cout, cout, 3, 3, 3});
+  K(s, p + ".out_layers.3.bias", {cout});
+  if (cin != cout) {
+    K(s, p + ".skip_connection.weight", {cout, cin, 1, 1, 1});
+    K(s, p + ".skip_connection.bias", {cout});
+  }
+}
+static void spec_attn(Spec& s, const std::string& p, int c, int g) {
+  K(s, p + ".norm1.weight", {c});
+  for (const char* n : {"q", "k", "v"}) {
+    K(s, p + ".attn." + n + ".weight", {c, c});
+    K(s, p + ".attn." + n + ".bias", {c});
+  }
+  K(s, p + ".attn.q_norm.weight", {c});
+  K(s, p + ".attn.k_norm.weight", {c});
+  K(s, p + ".attn.proj.weight", {c, c});
+  K(s, p + ".attn.proj.bias", {c});
+  K(s, p + ".norm2.weight", {c});
+  K(s, p + ".mlp.fc1.weight", {4 * c, c});
+  K(s, p + ".mlp.fc1.bias", {4 * c});
+  K(s, p + ".mlp.fc2.weight", {c, 4 * c});
+  K(s, p + ".mlp.fc2.bias", {c});
+  K(s, p + ".adaLN_modulation.1.weight", {7 * c, g});
+  K(s, p + ".adaLN_modulation.1.bias", {7 * c});
+}
+
+static int add_res(tm_model* m, const std::string& pfx, std::vector<int> seg, int cout) {
+  ResW r;
+  r.pfx = pfx; r.seg = seg; r.cout = cout;
+  for (int c : seg) { r.cin += c; r.cbi += (c + 7) / 8; }
+  r.has_skip = r.cin != cout;
+  r.emb_off = m->emb_tot;
+  m->emb_tot += 2 * cout;
+  m->res.push_back(r);
+  return (int)m->res.size() - 1;
+}
+static int add_attn(tm_model* m, const std::string& pfx, int C, int G) {
+  AttnW a;
+  a.pfx = pfx; a.C = C; a.G = G;
+  m->attn.push_back(a);
+  return (int)m->attn.size() - 1;
+}
+
+static int build_graph(tm_model* m) {
+  const tm_config& c = m->cfg;
+  Spec& s = m->spec;
+  const int E = c.embed_ch, ch0 = c.net_ch;
+  K(s, "time_embed.time_embed.0.weight", {E, ch0});
+  K(s, "time_embed.time_embed.0.bias", {E});
+  K(s, "time_embed.time_embed.2.weight", {E, E});
+  K(s, "time_embed.time_embed.2.bias", {E});
+  const int d = m->D, g = c.rna_num;
+  const int kzt[17] = {0, 1, 0, 0, 3, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0, 0, 9};   // MBAblocks.py:472
+  const int kz = kzt[c.rna_slc];
+  const std::string gp = "rna_blocks.0.0";
+  for (const char* n : {"q", "v"}) {
+    K(s, gp + ".attn." + n + ".weight", {d, d});
+    K(s, gp + ".attn." + n + ".bias", {d});
+  }
+  K(s, gp + ".attn.q_norm.weight", {d});
+  K(s, gp + ".attn.proj.weight", {d, d});
+  K(s, gp + ".attn.proj.bias", {d});
+  K(s, gp + ".norm2.weight", {d});
+  K(s, gp + ".mlp.fc1.weight", {4 * d, d});
+  K(s, gp + ".mlp.fc1.bias", {4 * d});
+  K(s, gp + ".mlp.fc2.weight", {d, 4 * d});
+  K(s, gp + ".mlp.fc2.bias", {d});
+  K(s, gp + ".down_z.weight", {g, g, kz, 3, 3});
+  K(s, gp + ".down_z.bias", {g});
+  if (c.vis_only) return TM_OK;
+  for (int rid = 1; rid < 4; ++rid) {
+    const std::string p = "rna_blocks." + std::to_string(rid) + ".1";
+    K(s, p + ".weight", {m->rw[rid], m->rw[rid - 1], 1, 3, 3});
+    K(s, p + ".bias", {m->rw[rid]});
+  }
+  K(s, "input_blocks.0.0.weight", {ch0, c.n_stain, 1, 3, 3});
+  K(s, "input_blocks.0.0.bias", {ch0});
+  const int L = m->L;
+  int ch = ch0, res = c.patch_size, k = 1;
+  std::vector<std::vector<int>> enc_ch(L);
+  enc_ch[0].push_back(ch);
+  for (int lvl = 0; lvl < L; ++lvl) {
+    const int rd = m->rw[L - 1 - lvl];
+    for (int i = 0; i < c.num_res_blocks; ++i) {
+      const int cout = c.ch_mult[lvl] * ch0;
+      const std::string p = "input_blocks." + std::to_string(k);
+      EncEntry e; e.lvl = lvl; e.cat = true;
+      spec_res(s, p + ".0", ch + rd, cout, E);
+      e.ops.push_back({0, add_res(m, p + ".0", {ch, rd}, cout), RS_SAME});
+      ch = cout;
+      if (res == c.attn_res) {
+        spec_attn(s, p + ".1", ch, rd);
+        e.ops.push_back({1, add_attn(m, p + ".1", ch, rd), 0});
+      }
+      m->enc.push_back(e);
+      enc_ch[lvl].push_back(ch);
+      ++k;
+    }
+    if (lvl != L - 1) {
+      res /= 2;
+      const std::string p = "input_blocks." + std::to_string(k) + ".0";
+      spec_res(s, p, ch, ch, E);
+      EncEntry e; e.lvl = lvl + 1; e.cat = false;
+      e.ops.push_back({0, add_res(m, p, {ch}, ch), RS_DOWN2});
+      m->enc.push_back(e);
+      enc_ch[lvl + 1].push_back(ch);
+      ++k;
+    }
+  }
+  spec_res(s, "middle_block.0", ch + m->rw[0], ch, E);
+  m->mid.push_back({0, add_res(m, "middle_block.0", {ch, m->rw[0]}, ch), RS_SAME});
+  spec_attn(s, "middle_block.1", ch, m->rw[0]);
+  m->mid.push_back({1, add_attn(m, "middle_block.1", ch, m->rw[0]), 0});
+  spec_res(s, "middle_block.2", ch, ch, E);
+  m->mid.push_back({0, add_res(m, "middle_block.2", {ch}, ch), RS_SAME});
+  k = 0;
+  for (int lvl = L - 1; lvl >= 0; --lvl) {
+    const int rd = m->rw[L - 1 - lvl];
+    for (int i = 0; i < c.num_res_blocks + 1; ++i) {
+      const int skip = enc_ch[lvl].back();
+      enc_ch[lvl].pop_back();
+      const int cout = c.ch_mult[lvl] * ch0;
+      const std::string p = "output_blocks." + std::to_string(k);
+      DecEntry e; e.lvl = lvl;
+      spec_res(s, p + ".0", ch + skip + rd, cout, E);
+      e.ops.push_back({0, add_res(m, p + ".0", {ch, skip, rd}, cout), RS_SAME});
+      ch = cout;
+      int nxt = 1;
+      if (res == c.attn_res) {
+        spec_attn(s, p + ".1", ch, rd);
+        e.ops.push_back({1, add_attn(m, p + ".1", ch, rd), 0});
+        nxt = 2;
+      }
+      if (lvl && i == c.num_res_blocks) {
+        res *= 2;
+        const std::string pu = p + "." + std::to_string(nxt);
+        spec_res(s, pu, ch, ch, E);
+        e.ops.push_back({0, add_res(m, pu, {ch}, ch), RS_UP2});
+      }
+      m->dec.push_back(e);
+      ++k;
+    }
+  }
+  K(s, "out.0.weight", {1, ch, 1, 1});
+  K(s, "out.2.weight", {c.n_stain, ch0, 1, 3, 3});
+  K(s, "out.2.bias", {c.n_stain});
+  return TM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int tm_version(void) { return TM_ABI_VERSION; }
+extern "C" const char* tm_last_error(void) { return g_err; }
+
+extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
+  if (!cfg || !out) return fail(TM_ERR_ARG, "null argument");
+  if (cfg->dtype != TM_DTYPE_F32) return fail(TM_ERR_ARG, "only TM_DTYPE_F32 is implemented");
+  if (cfg->patch_size != 64 || cfg->rna_slc != 4)
+    return fail(TM_ERR_ARG, "only patch_size=64, rna_slc=4 (checkpoint config) is implemented, got %d/%d",
+                cfg->patch_size, cfg->rna_slc);
+  if (cfg->n_stain < 1 || cfg->n_stain > 2 || cfg->rna_num < 1 || cfg->rna_num > 256)
+    return fail(TM_ERR_ARG, "n_stain/rna_num out of range");
+  if (cfg->net_ch % 64 || cfg->embed_ch % 64 || cfg->embed_ch > 1024)
+    return fail(TM_ERR_ARG, "net_ch must be a multiple of 64, embed_ch a multiple of 64 <= 1024");
+  tm_model* m = new tm_model();
+  m->cfg = *cfg;
+  m->z = (cfg->rna_slc + 1) / 2;
+  m->gn = cfg->patch_size / 16;
+  m->D = m->gn * m->gn * cfg->rna_slc;
+  m->rw[0] = cfg->rna_num;
+  for (int i = 0; i < 3; ++i) m->rw[i + 1] = RNA_TAIL[i];
+  int rc = build_graph(m);
+  if (rc != TM_OK) { delete m; return rc; }
+  for (auto& kv : m->spec) {
+    HostParam hp; hp.shape = kv.second;
+    m->host[kv.first] = hp;
+  }
+  *out = m;
+  return TM_OK;
+}
+
+extern "C" int tm_model_num_params(const tm_model* m) { return m ? (int)m->spec.size() : 0; }
+extern "C" const char* tm_model_param_key(const tm_model* m, int i) {
+  if (!m || i < 0 || i >= (int)m->spec.size()) return nullptr;
+  return m->spec[i].first.c_str();
+}
+
+extern "C" int tm_model_load_param(tm_model* m, const char* ref_key, const void* host_ptr, const int64_t* shape,
+                                   int ndim, int dtype) {
+  if (!m || !ref_key || !host_ptr || !shape) return fail(TM_ERR_ARG, "null argument");
+  if (m->finalized) return fail(TM_ERR_STATE, "model already finalized");
+  if (dtype != TM_DTYPE_F32) return fail(TM_ERR_ARG, "only fp32 parameters accepted");
+  auto it = m->host.find(ref_key);
+  if (it == m->host.end()) return fail(TM_ERR_KEY, "unexpected key '%s'", ref_key);
+  HostParam& hp = it->second;
+  if ((int)hp.shape.size() != ndim) return fail(TM_ERR_KEY, "key '%s': rank %d, expected %d", ref_key, ndim, (int)hp.shape.size());
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (hp.shape[i] != shape[i]) return fail(TM_ERR_KEY, "key '%s': dim %d is %lld, expected %lld", ref_key, i,
+                                             (long long)shape[i], (long long)hp.shape[i]);
+    n *= (size_t)shape[i];
+  }
+  hp.data.assign((const float*)host_ptr, (const float*)host_ptr + n);
+  hp.loaded = true;
+  return TM_OK;
+}
+
+// ---- arena packing -------------------------------------------------------------------------
+struct Packer {
+  std::vector<float> buf;
+  size_t reserve(size_t n) {                 // 64-byte aligned sub-allocations
+    size_t off = (buf.size() + 15) / 16 * 16;
+    buf.resize(off + n, 0.f);
+    return off;
+  }
+};
+struct Fix { const float** slot; size_t off; };
+
+static const std::vector<float>& P(tm_model* m, const std::string& k) { return m->host[k].data; }
+
+static void pack_conv(tm_model* m, Packer& pk, std::vector<Fix>& fx, ConvW& cw, const std::string& wkey,
+                      const std::string& bkey, int Cout, const std::vector<int>& seg, int taps) {
+  int cbi = 0;
+  for (int c : seg) cbi += (c + 7) / 8;
+  cw.Cout = Cout; cw.Cbi = cbi; cw.taps = taps; cw.ntile = (Cout + 63) / 64;
+  size_t off = pk.reserve(conv_pack_floats(Cout, cbi, taps));
+  conv_pack_host(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(), taps, pk.buf.data() + off);
+  fx.push_back({&cw.w, off});
+  size_t boff = pk.reserve((size_t)cw.ntile * 64);
+  const std::vector<float>& b = P(m, bkey);
+  for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
+  fx.push_back({&cw.bias, boff});
+}
+// rows of several [rows_i][Cin] matrices stacked into one conv1 weight
+static void pack_linear_stack(tm_model* m, Packer& pk, std::vector<Fix>& fx, ConvW& cw,
+                              const std::vector<std::string>& pfx, int rows_each, int Cin) {
+  const int Cout = rows_each * (int)pfx.size();
+  std::vector<float> w((size_t)Cout * Cin), b(Cout);
+  for (size_t i = 0; i < pfx.size(); ++i) {
+    const std::vector<float>& wi = P(m, pfx[i] + ".weight");
+    const std::vector<float>& bi = P(m, pfx[i] + ".bias");
+    memcpy(w.data() + i * (size_t)rows_each * Cin, wi.data(), (size_t)rows_each * Cin * sizeof(float));
+    memcpy(b.data() + i * rows_each, bi.data(), rows_each * sizeof(float));
+  }
+  int seg = Cin;
+  cw.Cout = Cout; cw.Cbi = (Cin + 7) / 8; cw.taps = 1; cw.ntile = (Cout + 63) / 64;
+  size_t off = pk.reserve(conv_pack_floats(Cout, cw.Cbi, 1));
+  conv_pack_host(w.data(), Cout, &seg, 1, 1, pk.buf.data() + off);
+  fx.push_back({&cw.w, off});
+  size_t boff = pk.reserve((size_t)cw.ntile * 64);
+  for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
+  fx.push_back({&cw.bias, boff});
+}
+static void pack_vec(Packer& pk, std::vector<Fix>& fx, const float** slot, const std::vector<float>& v,
+                     const std::vector<int>& seg) {
+  int cbi = 0;
+  for (int c : seg) cbi += (c + 7) / 8;
+  size_t off = pk.reserve((size_t)cbi * 8);
+  vec_pack_host(v.data(), seg.data(), (int)seg.size(), pk.buf.data() + off);
+  fx.push_back({slot, off});
+}
+static void pack_raw(Packer& pk, std::vector<Fix>& fx, const float** slot, const std::vector<float>& v) {
+  size_t off = pk.reserve(v.size());
+  memcpy(pk.buf.data() + off, v.data(), v.size() * sizeof(float));
+  fx.push_back({slot, off});
+}
+static void pack_transposed(Packer& pk, std::vector<Fix>& fx, const float** slot, const std::vector<float>& w,
+                            int rows, int cols) {           // [rows][cols] -> [cols][rows]
+  size_t off = pk.reserve((size_t)rows * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) pk.buf[off + (size_t)c * rows + r] = w[(size_t)r * cols + c];
+  fx.push_back({slot, off});
+}
+static void pack_direct(tm_model* m, Packer& pk, std::vector<Fix>& fx, DirectW& dw, const std::string& pfx, int Cout,
+                        int Cin, int kz, int ky, int kx) {
+  dw.Cin = Cin; dw.Cout = Cout; dw.kz = kz; dw.ky = ky; dw.kx = kx;
+  const int taps = kz * ky * kx, Cop = (Cout + 7) / 8 * 8;
+  const std::vector<float>& w = P(m, pfx + ".weight");
+  size_t off = pk.reserve((size_t)taps * Cin * Cop);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < taps; ++t)
+        pk.buf[off + ((size_t)t * Cin + ci) * Cop + co] = w[((size_t)co * Cin + ci) * taps + t];
+  fx.push_back({&dw.w, off});
+  pack_raw(pk, fx, &dw.bias, P(m, pfx + ".bias"));
+}
+
+extern "C" int tm_model_finalize(tm_model* m) {
+  if (!m) return fail(TM_ERR_ARG, "null model");
+  if (m->finalized) return fail(TM_ERR_STATE, "already finalized");
+  for (auto& kv : m->spec)
+    if (!m->host[kv.first].loaded) return fail(TM_ERR_KEY, "missing key '%s' (strict load)", kv.first.c_str());
+  const tm_config& c = m->cfg;
+  Packer pk;
+  std::vector<Fix> fx;
+  pack_raw(pk, fx, &m->te_w1, P(m, "time_embed.time_embed.0.weight"));
+  pack_raw(pk, fx, &m->te_b1, P(m, "time_embed.time_embed.0.bias"));
+  pack_raw(pk, fx, &m->te_w2, P(m, "time_embed.time_embed.2.weight"));
+  pack_raw(pk, fx, &m->te_b2, P(m, "time_embed.time_embed.2.bias"));
+  {
+    const std::string g = "rna_blocks.0.0";
+    const int d = m->D;
+    pack_transposed(pk, fx, &m->gene.wq_t, P(m, g + ".attn.q.weight"), d, d);
+    pack_raw(pk, fx, &m->gene.bq, P(m, g + ".attn.q.bias"));
+    pack_transposed(pk, fx, &m->gene.wv_t, P(m, g + ".attn.v.weight"), d, d);
+    pack_raw(pk, fx, &m->gene.bv, P(m, g + ".attn.v.bias"));
+    pack_raw(pk, fx, &m->gene.qnorm, P(m, g + ".attn.q_norm.weight"));
+    pack_transposed(pk, fx, &m->gene.wp_t, P(m, g + ".attn.proj.weight"), d, d);
+    pack_raw(pk, fx, &m->gene.bp, P(m, g + ".attn.proj.bias"));
+    pack_raw(pk, fx, &m->gene.norm2, P(m, g + ".norm2.weight"));
+    pack_transposed(pk, fx, &m->gene.w1_t, P(m, g + ".mlp.fc1.weight"), 4 * d, d);
+    pack_raw(pk, fx, &m->gene.b1, P(m, g + ".mlp.fc1.bias"));
+    pack_transposed(pk, fx, &m->gene.w2_t, P(m, g + ".mlp.fc2.weight"), d, 4 * d);
+    pack_raw(pk, fx, &m->gene.b2, P(m, g + ".mlp.fc2.bias"));
+    pack_direct(m, pk, fx, m->downz, g + ".down_z", c.rna_num, c.rna_num, (int)m->host[g + ".down_z.weight"].shape[2], 3, 3);
+  }
+  if (!c.vis_only) {
+    for (int rid = 1; rid < 4; ++rid)
+      pack_direct(m, pk, fx, m->pyr[rid - 1], "rna_blocks." + std::to_string(rid) + ".1", m->rw[rid], m->rw[rid - 1], 1, 3, 3);
+    pack_direct(m, pk, fx, m->stem, "input_blocks.0.0", c.net_ch, c.n_stain, 1, 3, 3);
+    pack_direct(m, pk, fx, m->head, "out.2", c.n_stain, c.net_ch, 1, 3, 3);
+    pack_raw(pk, fx, &m->out_norm, P(m, "out.0.weight"));
+    // all emb_layers as one [emb_tot][E] matrix
+    {
+      const int E = c.embed_ch;
+      size_t woff = pk.reserve((size_t)m->emb_tot * E), boff = pk.reserve(m->emb_tot);
+      for (ResW& r : m->res) {
+        const std::vector<float>& w = P(m, r.pfx + ".emb_layers.1.weight");
+        const std::vector<float>& b = P(m, r.pfx + ".emb_layers.1.bias");
+        memcpy(pk.buf.data() + woff + (size_t)r.emb_off * E, w.data(), w.size() * sizeof(float));
+        memcpy(pk.buf.data() + boff + r.emb_off, b.data(), b.size() * sizeof(float));
+      }
+      fx.push_back({&m->emb_w, woff});
+      fx.push_back({&m->emb_b, boff});
+    }
+    for (ResW& r : m->res) {
+      pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27);
+      pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27);
+      if (r.has_skip)
+        pack_conv(m, pk, fx, r.skip, r.pfx + ".skip_connection.weight", r.pfx + ".skip_connection.bias", r.cout, r.seg, 1);
+      pack_vec(pk, fx, &r.n1, P(m, r.pfx + ".in_layers.0.weight"), r.seg);
+      pack_raw(pk, fx, &r.n2, P(m, r.pfx + ".out_layers.0.weight"));
+    }
+    for (AttnW& a : m->attn) {
+      pack_linear_stack(m, pk, fx, a.ada, {a.pfx + ".adaLN_modulation.1"}, 7 * a.C, a.G);
+      pack_linear_stack(m, pk, fx, a.q, {a.pfx + ".attn.q"}, a.C, a.C);
+      pack_linear_stack(m, pk, fx, a.kv, {a.pfx + ".attn.k", a.pfx + ".attn.v"}, a.C, a.C);
+      pack_linear_stack(m, pk, fx, a.proj, {a.pfx + ".attn.proj"}, a.C, a.C);
+      pack_linear_stack(m, pk, fx, a.fc1, {a.pfx + ".mlp.fc1"}, 4 * a.C, a.C);
+      pack_linear_stack(m, pk, fx, a.fc2, {a.pfx + ".mlp.fc2"}, a.C, 4 * a.C);
+      pack_raw(pk, fx, &a.n1, P(m, a.pfx + ".norm1.weight"));
+      pack_raw(pk, fx, &a.n2, P(m, a.pfx + ".norm2.weight"));
+      pack_raw(pk, fx, &a.qn, P(m, a.pfx + ".attn.q_norm.weight"));
+      pack_raw(pk, fx, &a.kn, P(m, a.pfx + ".attn.k_norm.weight"));
+    }
+  }
+  m->arena_floats = (pk.buf.size() + 15) / 16 * 16;
+  pk.buf.resize(m->arena_floats, 0.f);
+  HIP_TRY(hipMalloc((void**)&m->arena, m->arena_floats * sizeof(float)));
+  HIP_TRY(hipMemcpy(m->arena, pk.buf.data(), m->arena_floats * sizeof(float), hipMemcpyHostToDevice));
+  for (Fix& f : fx) *f.slot = m->arena + f.off;
+  m->host.clear();
+  m->finalized = true;
+  return TM_OK;
+}
+
+extern "C" size_t tm_model_arena_bytes(const tm_model* m) { return m ? m->arena_floats * sizeof(float) : 0; }
+extern "C" void* tm_model_arena_ptr(tm_model* m) { return m ? (void*)m->arena : nullptr; }
+
+extern "C" int tm_model_destroy(tm_model* m) {
+  if (!m) return TM_OK;
+  if (m->arena) (void)hipFree(m->arena);
+  delete m;
+  return TM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// executor
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+  tm_model* m;
+  char* base = nullptr;
+  size_t cap = 0, top = 0, peak = 0;
+  bool dry = false;
+  hipStream_t s = nullptr;
+  int b = 0, p1 = 0, p2 = 0, Ne = 0, Nd = 0;
+  hipError_t err = hipSuccess;
+  const float* ss = nullptr;      // [b][emb_tot]
+
+  float* alloc_f(size_t nfloats) {
+    size_t off = (top + 255) / 256 * 256;
+    top = off + nfloats * sizeof(float);
+    if (top > peak) peak = top;
+    if (dry) return (float*)(uintptr_t)256;     // never dereferenced
+    if (top > cap) { if (err == hipSuccess) err = hipErrorOutOfMemory; return (float*)base; }
+    return (float*)(base + off);
+  }
+  TV tensor(int N, int C, int Z, int S) {
+    TV t;
+    t.N = N; t.C = C; t.Cb = (C + 7) / 8; t.Z = Z; t.H = S; t.W = S;
+    t.nstride = (long)t.Cb * t.plane();
+    t.p = alloc_f((size_t)N * t.nstride);
+    return t;
+  }
+  void check(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
+};
+
+struct Src { TV t; bool collage; };
+
+// Debug taps: with TM_DEBUG_DIR set, every block output is written (NCDHW fp32, raw) to
+// $TM_DEBUG_DIR/<name>.bin after a stream sync.  Test/diagnostic aid only.
+static const char* debug_dir() {
+  static const char* d = getenv("TM_DEBUG_DIR");
+  return (d && *d) ? d : nullptr;
+}
+static void dump_tv(Ctx& cx, const std::string& name, const TV& t) {
+  if (cx.dry || !debug_dir()) return;
+  const size_t n = (size_t)t.N * t.C * t.Z * t.H * t.W;
+  float* dev = nullptr;
+  if (hipMalloc((void**)&dev, n * sizeof(float)) != hipSuccess) return;
+  std::vector<float> host(n);
+  if (launch_from_cb8(t, dev, cx.s) == hipSuccess && hipStreamSynchronize(cx.s) == hipSuccess &&
+      hipMemcpy(host.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
+    const std::string path = std::string(debug_dir()) + "/" + name + ".bin";
+    if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(host.data(), sizeof(float), n, f); fclose(f); }
+  }
+  (void)hipFree(dev);
+}
+
+static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags) {
+  if (cx.dry) return;
+  ConvLaunch L;
+  L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
+  cx.check(launch_conv_mfma(L, cx.s));
+}
+
+// ResBlock._forward (model/MBAblocks.py:237-299)
+static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, int per_image, int S_out, int mode,
+                    TV* out_opt) {
+  tm_model* m = cx.m;
+  const int Z = m->z;
+  TV out = out_opt ? *out_opt : cx.tensor(N, w.cout, Z, S_out);
+  const size_t mark = cx.top;
+  int cin_pad = w.cbi * 8;
+  TV A = cx.tensor(N, cin_pad, Z, S_out);
+  TV raw;
+  const bool need_raw = w.has_skip || mode != RS_SAME;
+  if (need_raw) raw = cx.tensor(N, cin_pad, Z, S_out);
+  if (!cx.dry) {
+    PrepLaunch P;
+    P.nsrc = (int)src.size();
+    for (size_t i = 0; i < src.size(); ++i) {
+      P.src[i].p = src[i].t.p; P.src[i].nstride = src[i].t.nstride; P.src[i].Cb = src[i].t.Cb;
+      P.src[i].collage = src[i].collage ? 1 : 0;
+    }
+    P.resample = mode; P.N = N; P.Z = Z; P.S = S_out; P.p1 = cx.p1; P.p2 = cx.p2;
+    P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
+    P.out = A.p; P.out_nstride = A.nstride;
+    if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
+    cx.check(launch_prep(P, cx.s));
+  }
+  TV H1 = cx.tensor(N, w.cout, Z, S_out);
+  run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0);
+  TV A2 = cx.tensor(N, w.cout, Z, S_out);
+  if (!cx.dry) {
+    PrepLaunch P;
+    P.nsrc = 1;
+    P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
+    P.N = N; P.Z = Z; P.S = S_out;
+    P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
+    P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
+    P.mod_stride = m->emb_tot;
+    P.out = A2.p; P.out_nstride = A2.nstride;
+    cx.check(launch_prep(P, cx.s));
+  }
+  if (w.has_skip) {
+    run_conv(cx, raw, w.skip, out, nullptr, nullptr, 0);
+    run_conv(cx, A2, w.c2, out, &out, nullptr, 0);
+  } else if (mode != RS_SAME) {
+    run_conv(cx, A2, w.c2, out, &raw, nullptr, 0);
+  } else {
+    run_conv(cx, A2, w.c2, out, &src[0].t, nullptr, 0);
+  }
+  cx.top = mark;
+  return out;
+}
+
+// AttnBlock._forward with cond (model/MBAblocks.py:484-489); x updated in place
+static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_image) {
+  const size_t mark = cx.top;
+  const int N = x.N, Z = x.Z, S = x.H, C = w.C, cb = C / 8;
+  TV cact = cx.tensor(N, (w.G + 7) / 8 * 8, Z, S);
+  if (!cx.dry) {
+    PrepLaunch P;
+    P.nsrc = 1;
+    P.src[0].p = cond.t.p; P.src[0].nstride = cond.t.nstride; P.src[0].Cb = cond.t.Cb;
+    P.src[0].collage = cond.collage ? 1 : 0;
+    P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = 1; P.per_image = per_image;
+    P.out = cact.p; P.out_nstride = cact.nstride;
+    cx.check(launch_prep(P, cx.s));
+  }
+  TV mod = cx.tensor(N, 7 * C, Z, S);
+  run_conv(cx, cact, w.ada, mod, nullptr, nullptr, 0);
+  // chunk order (MBAblocks.py:487): shift_msa, scale_msa, gate_msa, crss_cnd, shift_mlp, scale_mlp, gate_mlp
+  TV sh_a = mod.blocks(0 * cb, cb), sc_a = mod.blocks(1 * cb, cb), g_a = mod.blocks(2 * cb, cb);
+  TV crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
+  TV xa = cx.tensor(N, C, Z, S);
+  auto modulate = [&](const float* nw, const TV& sc, const TV& sh, TV dst) {
+    if (cx.dry) return;
+    PrepLaunch P;
+    P.nsrc = 1;
+    P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+    P.N = N; P.Z = Z; P.S = S; P.norm_w = nw; P.inv_c = 1.0f / (float)C; P.per_image = per_image;
+    P.mod = MOD_VOXEL; P.mod_scale = sc.p; P.mod_shift = sh.p; P.mod_stride = mod.nstride;
+    P.out = dst.p; P.out_nstride = dst.nstride;
+    cx.check(launch_prep(P, cx.s));
+  };
+  modulate(w.n1, sc_a, sh_a, xa);
+  TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, S), o = cx.tensor(N, C, Z, S);
+  run_conv(cx, xa, w.q, q, nullptr, nullptr, 0);
+  run_conv(cx, crs, w.kv, kv, nullptr, nullptr, 0);
+  if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, o, cx.s));
+  run_conv(cx, o, w.proj, x, &x, &g_a, 0);
+  modulate(w.n2, sc_m, sh_m, xa);
+  TV h1 = cx.tensor(N, 4 * C, Z, S);
+  run_conv(cx, xa, w.fc1, h1, nullptr, nullptr, EPI_GELU);
+  run_conv(cx, h1, w.fc2, x, &x, &g_m, 0);
+  cx.top = mark;
+}
+
+static void run_direct(Ctx& cx, const DirectW& w, const float* x, Acc5 ax, float* y, Acc5 ay, int N, int Zin, int Zout,
+                       int S, int pz, int silu_in, int up2) {
+  if (cx.dry) return;
+  DirectLaunch L;
+  L.x = x; L.ax = ax; L.y = y; L.ay = ay; L.w = w.w; L.bias = w.bias;
+  L.N = N; L.Cin = w.Cin; L.Cout = w.Cout; L.Zin = Zin; L.Zout = Zout; L.S = S;
+  L.kz = w.kz; L.ky = w.ky; L.kx = w.kx; L.pz = pz; L.py = 1; L.px = 1;
+  L.silu_in = silu_in; L.up2_out = up2;
+  cx.check(launch_conv_direct(L, cx.s));
+}
+
+static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* rna, float* pred, float* pred2) {
+  tm_model* m = cx.m;
+  const tm_config& c = m->cfg;
+  const int Z = m->z, L = m->L, ps = c.patch_size, Ne = cx.Ne, Nd = cx.Nd, b = cx.b;
+  const int ne_img = cx.p1 * cx.p2, nd_img = (cx.p1 - 1) * (cx.p2 - 1);
+  // ---- time embedding + all emb_layers ----
+  float* te = cx.alloc_f((size_t)b * c.embed_ch);
+  float* ss = cx.alloc_f((size_t)b * m->emb_tot);
+  cx.ss = ss;
+  if (!cx.dry) {
+    cx.check(launch_time_embed(t, b, c.net_ch, c.embed_ch, m->te_w1, m->te_b1, m->te_w2, m->te_b2, te, cx.s));
+    cx.check(launch_emb_all(te, b, c.embed_ch, m->emb_w, m->emb_b, m->emb_tot, ss, cx.s));
+  }
+  // ---- RNA pyramid (get_rna, model/unet_ours.py:298-323) ----
+  float* tok = cx.alloc_f((size_t)Ne * c.rna_num * m->D);
+  if (!cx.dry) cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok, nullptr, 0, c.rna_slc, cx.s));
+  TV rl[4];
+  int S = m->gn * 2;
+  rl[0] = cx.tensor(Ne, m->rw[0], Z, S);
+  if (!cx.dry) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));
+  run_direct(cx, m->downz, tok, acc_ncdhw(c.rna_num, c.rna_slc, m->gn, m->gn), rl[0].p, acc_cb8(rl[0]), Ne, c.rna_slc,
+             Z, m->gn, 0, 0, 1);
+  for (int i = 1; i < 4; ++i) {
+    rl[i] = cx.tensor(Ne, m->rw[i], Z, S * 2);
+    run_direct(cx, m->pyr[i - 1], rl[i - 1].p, acc_cb8(rl[i - 1]), rl[i].p, acc_cb8(rl[i]), Ne, Z, Z, S, 0, 1, 1);
+    S *= 2;
+  }
+  for (int i = 0; i < 4; ++i) { TV v = rl[i]; v.C = m->rw[i]; dump_tv(cx, "rna." + std::to_string(i), v); }
+  // ---- stem ----
+  std::vector<std::vector<TV>> skips(L);
+  TV h = cx.tensor(Ne, c.net_ch, Z, ps);
+  run_direct(cx, m->stem, x, acc_ncdhw(c.n_stain, Z, ps, ps), h.p, acc_cb8(h), Ne, Z, Z, ps, 0, 0, 0);
+  skips[0].push_back(h);
+  dump_tv(cx, "stem", h);
+  // ---- encoder ----
+  for (const EncEntry& e : m->enc) {
+    const TV& cond = rl[L - 1 - e.lvl];
+    const int So = ps >> e.lvl;
+    std::vector<Src> src;
+    src.push_back({h, false});
+    if (e.cat) src.push_back({cond, false});
+    for (const Op& op : e.ops) {
+      if (op.kind == 0) h = res_block(cx, m->res[op.idx], src, Ne, ne_img, So, op.mode, nullptr);
+      else attn_block(cx, m->attn[op.idx], h, {cond, false}, ne_img);
+    }
+    skips[e.lvl].push_back(h);
+    const Op& last = e.ops.back();
+    dump_tv(cx, last.kind == 0 ? m->res[last.idx].pfx : m->attn[last.idx].pfx, h);
+  }
+  // ---- middle ----
+  {
+    std::vector<Src> src = {{h, false}, {rl[0], false}};
+    const int So = ps >> (L - 1);
+    h = res_block(cx, m->res[m->mid[0].idx], src, Ne, ne_img, So, RS_SAME, nullptr);
+    attn_block(cx, m->attn[m->mid[1].idx], h, {rl[0], false}, ne_img);
+    std::vector<Src> src2 = {{h, false}};
+    h = res_block(cx, m->res[m->mid[2].idx], src2, Ne, ne_img, So, RS_SAME, nullptr);
+    dump_tv(cx, "middle_block", h);
+  }
+  // ---- decoder(s) ----
+  auto decode = [&](bool col, float* outp) {
+    const size_t mark = cx.top;
+    const int N = col ? Nd : Ne, per = col ? nd_img : ne_img;
+    std::vector<std::vector<TV>> st = skips;
+    TV hd = h;
+    bool hd_col = col;                 // only the middle output still lives on the encoder grid
+    for (const DecEntry& e : m->dec) {
+      const int So = ps >> e.lvl;
+      Src cond = {rl[L - 1 - e.lvl], col};
+      std::vector<Src> src = {{hd, hd_col}, {st[e.lvl].back(), col}, cond};
+      st[e.lvl].pop_back();
+      for (const Op& op : e.ops) {
+        if (op.kind == 0) {
+          if (op.mode == RS_SAME) hd = res_block(cx, m->res[op.idx], src, N, per, So, RS_SAME, nullptr);
+          else { std::vector<Src> s1 = {{hd, false}}; hd = res_block(cx, m->res[op.idx], s1, N, per, So * 2, RS_UP2, nullptr); }
+        } else attn_block(cx, m->attn[op.idx], hd, cond, per);
+      }
+      hd_col = false;
+      if (col) { const std::string& p0 = m->res[e.ops[0].idx].pfx; dump_tv(cx, p0.substr(0, p0.size() - 2), hd); }
+    }
+    // head: RMSNorm -> SiLU -> Conv3d(1,3,3) -> 'b s z h w -> b (s z) h w'  (unet_ours.py:271-275,423-424)
+    TV A = cx.tensor(N, c.net_ch, Z, ps);
+    if (!cx.dry) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = hd.p; P.src[0].nstride = hd.nstride; P.src[0].Cb = hd.Cb;
+      P.N = N; P.Z = Z; P.S = ps; P.norm_w = m->out_norm; P.inv_c = 1.0f / (float)c.net_ch; P.act = 1; P.per_image = per;
+      P.out = A.p; P.out_nstride = A.nstride;
+      cx.check(launch_prep(P, cx.s));
+    }
+    run_direct(cx, m->head, A.p, acc_cb8(A), outp, acc_ncdhw(c.n_stain, Z, ps, ps), N, Z, Z, ps, 0, 0, 0);
+    cx.top = mark;
+  };
+  decode(true, pred);
+  if (pred2) decode(false, pred2);
+  return TM_OK;
+}
+
+static int check_fwd_args(const tm_model* m, int b, int p1, int p2) {
+  if (!m) return fail(TM_ERR_ARG, "null model");
+  if (!m->finalized) return fail(TM_ERR_STATE, "tm_model_finalize has not been called");
+  if (m->cfg.vis_only) return fail(TM_ERR_STATE, "attention-map model has no UNet forward");
+  if (b < 1 || p1 < 2 || p2 < 2) return fail(TM_ERR_ARG, "need b >= 1 and p1, p2 >= 2 (got %d, %d, %d)", b, p1, p2);
+  return TM_OK;
+}
+
+extern "C" size_t tm_workspace_bytes(const tm_model* m, int b, int p1, int p2, int want_pred2) {
+  if (check_fwd_args(m, b, p1, p2) != TM_OK) return 0;
+  Ctx cx;
+  cx.m = const_cast<tm_model*>(m); cx.dry = true;
+  cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
+  forward_impl(cx, nullptr, nullptr, nullptr, (float*)256, want_pred2 ? (float*)256 : nullptr);
+  return cx.peak + 256;
+}
+
+extern "C" int tm_unet_forward(tm_model* m, const void* x, const int64_t* t, const void* rna_dense, int b, int p1,
+                               int p2, void* pred, void* pred2_or_null, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  int rc = check_fwd_args(m, b, p1, p2);
+  if (rc != TM_OK) return rc;
+  if (!x || !t || !rna_dense || !pred || !workspace) return fail(TM_ERR_ARG, "null tensor argument");
+  Ctx cx;
+  cx.m = m; cx.s = (hipStream_t)stream;
+  cx.base = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+  cx.cap = workspace_bytes - (size_t)(cx.base - (char*)workspace);
+  cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
+  const size_t need = tm_workspace_bytes(m, b, p1, p2, pred2_or_null != nullptr);
+  if (workspace_bytes < need) return fail(TM_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  forward_impl(cx, (const float*)x, t, (const float*)rna_dense, (float*)pred, (float*)pred2_or_null);
+  if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
+  return TM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int tm_sampler_step(const tm_step_coefs* c, const void* x_patches, const void* eps, const void* noise,
+                               void* x_prev_img, int b, int P1, int P2, int C, int ps, int mode, void* stream) {
+  if (!c || !x_patches || !eps || !x_prev_img) return fail(TM_ERR_ARG, "null argument");
+  if (b < 1 || P1 < 1 || P2 < 1 || C < 1 || ps < 2 || (ps & 1)) return fail(TM_ERR_ARG, "bad geometry");
+  if (mode != TM_SAMPLE_DDPM && mode != TM_SAMPLE_DDIM) return fail(TM_ERR_ARG, "mode must be DDPM or DDIM");
+  StepCoefs k = {c->sqrt_recip_alphas_cumprod, c->sqrt_recipm1_alphas_cumprod, c->posterior_mean_coef1,
+                 c->posterior_mean_coef2, c->sigma, c->sqrt_alpha_bar_prev, c->sqrt_one_minus_alpha_bar_prev};
+  HIP_TRY(launch_sampler_step(k, (const float*)x_patches, (const float*)eps, (const float*)noise, (float*)x_prev_img,
+                              b, P1, P2, C, ps, mode, (hipStream_t)stream));
+  return TM_OK;
+}
+
+extern "C" int tm_pad_patchify(const void* img, void* patches, int b, int C, int P1, int P2, int ps, float pad,
+                               void* stream) {
+  if (!img || !patches || b < 1 || P1 < 1 || P2 < 1 || C < 1 || ps < 2 || (ps & 1)) return fail(TM_ERR_ARG, "bad argument");
+  HIP_TRY(launch_pad_patchify((const float*)img, (float*)patches, b, C, P1, P2, ps, pad, (hipStream_t)stream));
+  return TM_OK;
+}
+
+extern "C" size_t tm_gene_attn_workspace_bytes(const tm_model* m, int B) { (void)m; (void)B; return 256; }
+
+extern "C" int tm_gene_attn(tm_model* m, const void* rna_dense, int B, void* attn_out, void* rna_mid, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (!m || !rna_dense || !attn_out || B < 1) return fail(TM_ERR_ARG, "bad argument");
+  if (!m->finalized) return fail(TM_ERR_STATE, "tm_model_finalize has not been called");
+  const tm_config& c = m->cfg;
+  const int G = c.rna_num, zs = c.rna_slc;
+  float* ao = (float*)attn_out;
+  hipStream_t s = (hipStream_t)stream;
+  // three slice-pair masks then the unmasked map (model/unet_attn.py:162-172)
+  for (int i = 0; i < 4; ++i) {
+    const int lo = (i < 3) ? i : 0, hi = (i < 3) ? i + 2 : zs;
+    HIP_TRY(launch_gene_attn((const float*)rna_dense, B, m->gn, zs, G, m->gene, nullptr, ao + (size_t)i * B * G * G, lo, hi, s));
+  }
+  if (rna_mid) HIP_TRY(launch_rna_mid((const float*)rna_dense, B, m->gn, zs, G, (float*)rna_mid, s));
+  return TM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// single-operator entry points (tests)
+// ------------------------------------------------------------------------------------------
+static TV view_cb8(void* p, int N, int C, int Z, int H, int W) {
+  TV t;
+  t.p = (float*)p; t.N = N; t.C = C; t.Cb = (C + 7) / 8; t.Z = Z; t.H = H; t.W = W;
+  t.nstride = (long)t.Cb * t.plane();
+  return t;
+}
+extern "C" int tm_op_to_cb8(const void* x, void* y, int N, int C, int Z, int H, int W, void* stream) {
+  HIP_TRY(launch_to_cb8((const float*)x, view_cb8(y, N, C, Z, H, W), (hipStream_t)stream));
+  return TM_OK;
+}
+extern "C" int tm_op_from_cb8(const void* x, void* y, int N, int C, int Z, int H, int W, void* stream) {
+  HIP_TRY(launch_from_cb8(view_cb8(const_cast<void*>(x), N, C, Z, H, W), (float*)y, (hipStream_t)stream));
+  return TM_OK;
+}
+extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
+                               int Cout, int Z, int S, int ksize, int tile_variant, void* stream) {
+  if (ksize != 1 && ksize != 3) return fail(TM_ERR_ARG, "ksize must be 1 or 3");
+  const int taps = ksize == 3 ? 27 : 1;
+  ConvW cw;
+  cw.Cout = Cout; cw.Cbi = (Cin + 7) / 8; cw.taps = taps; cw.ntile = (Cout + 63) / 64;
+  std::vector<float> pk(conv_pack_floats(Cout, cw.Cbi, taps)), bp((size_t)cw.ntile * 64, 0.f);
+  conv_pack_host((const float*)w_host, Cout, &Cin, 1, taps, pk.data());
+  memcpy(bp.data(), bias_host, Cout * sizeof(float));
+  float *dw = nullptr, *db = nullptr;
+  HIP_TRY(hipMalloc((void**)&dw, pk.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&db, bp.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  cw.w = dw; cw.bias = db;
+  ConvLaunch L;
+  L.x = view_cb8(const_cast<void*>(x_cb8), N, Cin, Z, S, S);
+  L.w = cw;
+  L.y = view_cb8(y_cb8, N, Cout, Z, S, S);
+  L.tile_variant = tile_variant;
+  hipError_t e = launch_conv_mfma(L, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(dw); (void)hipFree(db);
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv_mfma: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv_mfma execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}
+extern "C" int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N, int Cin,
+                                 int Cout, int Zin, int S, int kz, int ky, int kx, int pz, int py, int px, int silu_in,
+                                 int up2_out, void* stream) {
+  const int taps = kz * ky * kx, Cop = (Cout + 7) / 8 * 8;
+  const int Zout = Zin + 2 * pz - kz + 1;
+  if (Zout < 1 || py != ky / 2 || px != kx / 2) return fail(TM_ERR_ARG, "unsupported geometry");
+  std::vector<float> wt((size_t)taps * Cin * Cop, 0.f);
+  const float* w = (const float*)w_host;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < taps; ++t) wt[((size_t)t * Cin + ci) * Cop + co] = w[((size_t)co * Cin + ci) * taps + t];
+  float *dw = nullptr, *db = nullptr;
+  HIP_TRY(hipMalloc((void**)&dw, wt.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&db, Cout * sizeof(float)));
+  HIP_TRY(hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
+  DirectLaunch L;
+  L.x = (const float*)x; L.ax = acc_ncdhw(Cin, Zin, S, S);
+  const int So = up2_out ? 2 * S : S;
+  L.y = (float*)y; L.ay = acc_ncdhw(Cout, Zout, So, So);
+  L.w = dw; L.bias = db; L.N = N; L.Cin = Cin; L.Cout = Cout; L.Zin = Zin; L.Zout = Zout; L.S = S;
+  L.kz = kz; L.ky = ky; L.kx = kx; L.pz = pz; L.py = py; L.px = px; L.silu_in = silu_in; L.up2_out = up2_out;
+  hipError_t e = launch_conv_direct(L, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(dw); (void)hipFree(db);
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv_direct: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv_direct execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}

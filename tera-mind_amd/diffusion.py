@@ -1,0 +1,203 @@
+"""Sampler host logic of the path, with the reference's call surface.
+
+`SpacedDiffusionBeatGans.sample(model=, shape=, noise=, pos=, r_start=, imgs=, idx=, patch_size=,
+model_kwargs=)` follows reference diffusion/base.py:291-332 (sample), :500-631 (loop driver)
+and diffusion/diffusion.py:60-161 (spacing + timestep map).  The integer paths
+(`space_timesteps`, `timestep_map`, `sparse_repatch`) and the float64 coefficient tables are
+host Python / numpy, exactly as in the reference; the per-pixel update, the pad+patchify
+and the UNet run in libteramind_hip.so.
+
+Two keyword-only extensions make fixed-noise parity runs possible (seam S2 of SURVEY.md
+section 8b): `x_T=` supplies the initial state of mode A (the reference draws it with
+th.randn, base.py:566) and `step_noise=` the per-step DDPM noise (base.py:478).
+"""
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------
+# integer / float64 host paths
+# ------------------------------------------------------------------------------------------
+def space_timesteps(num_timesteps: int, section_counts) -> set:
+    """Retained timestep set (reference diffusion/diffusion.py:5-57).  "ddimN": the smallest
+    integer stride giving exactly N steps; list: per-section `round(k * frac_stride)`
+    (Python round = banker's rounding, as in the reference)."""
+    if isinstance(section_counts, str):
+        if section_counts[:4] in ("ddim", "fdpm"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                picked = range(0, num_timesteps, stride)
+                if len(picked) == want:
+                    return set(picked)
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(v) for v in section_counts.split(",")]
+    base, extra = divmod(num_timesteps, len(section_counts))
+    out, start = [], 0
+    for sec, count in enumerate(section_counts):
+        size = base + (1 if sec < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        pos = 0.0
+        for _ in range(count):
+            out.append(start + round(pos))
+            pos += stride
+        start += size
+    return set(out)
+
+
+def named_beta_schedule(name: str, T: int) -> np.ndarray:
+    """reference diffusion/base.py:649-667 ('linear' is the only schedule the path uses)."""
+    if name != "linear":
+        raise NotImplementedError(f"beta schedule {name!r}")
+    scale = 1000 / T
+    return np.linspace(scale * 0.0001, scale * 0.02, T, dtype=np.float64)
+
+
+def sparse_repatch(rna, sz: int):
+    """COO coordinate remap image grid -> patch grid (reference diffusion/base.py:111-120).
+    Bit-exact integer arithmetic; unlike the reference it does not mutate `crd` in place."""
+    dat, crd, ssz = rna
+    p1, p2 = ssz[1] // sz, ssz[2] // sz
+    crd = crd.long()
+    new0 = crd[0] * (p1 * p2) + torch.div(crd[1], sz, rounding_mode="floor") * p2 + torch.div(crd[2], sz, rounding_mode="floor")
+    out = torch.stack([new0, crd[1] % sz, crd[2] % sz, crd[3]])
+    return dat, out, torch.Size([ssz[0] * p1 * p2, sz, sz, ssz[-1]])
+
+
+class SpacedDiffusionBeatGans:
+    """Tables of GaussianDiffusionBeatGans.__init__ (base.py:64-109) over the re-derived betas
+    of SpacedDiffusionBeatGans.__init__ (diffusion.py:76-94); float64 numpy throughout."""
+
+    def __init__(self, T: int, gen_type: str = "ddim", T_train: int = 1000, beta_scheduler: str = "linear"):
+        if gen_type not in ("ddpm", "ddim"):
+            raise NotImplementedError(gen_type)
+        self.gen_type = gen_type
+        self.original_num_steps = T_train
+        # TrainConfig._make_diffusion_conf (config.py:190-197)
+        self.use_timesteps = space_timesteps(T_train, [T] if gen_type == "ddpm" else f"ddim{T}")
+        base_betas = named_beta_schedule(beta_scheduler, T_train)
+        base_acp = np.cumprod(1.0 - base_betas, axis=0)
+        last, new_betas, self.timestep_map = 1.0, [], []
+        for i, acp in enumerate(base_acp):
+            if i in self.use_timesteps:
+                new_betas.append(1 - acp / last)
+                last = acp
+                self.timestep_map.append(i)
+        betas = np.array(new_betas, dtype=np.float64)
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.betas = self._betas = betas
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        # ModelVarType.fixed_large (base.py:403-413)
+        self.model_log_variance = np.log(np.append(self.posterior_variance[1], betas[1:]))
+
+    # ---- per-step scalars handed to the kernel ------------------------------------------------
+    def step_coefs(self, i: int) -> _lib.TmStepCoefs:
+        """Table entries at index i cast `.float()` (base.py:643); sigma and the two DDIM square
+        roots are evaluated in float32 torch exactly like the reference's tensor expressions."""
+        f32 = lambda a: torch.tensor(np.float32(a[i]))
+        c = _lib.TmStepCoefs()
+        c.sqrt_recip_alphas_cumprod = float(f32(self.sqrt_recip_alphas_cumprod))
+        c.sqrt_recipm1_alphas_cumprod = float(f32(self.sqrt_recipm1_alphas_cumprod))
+        c.posterior_mean_coef1 = float(f32(self.posterior_mean_coef1))
+        c.posterior_mean_coef2 = float(f32(self.posterior_mean_coef2))
+        c.sigma = float(torch.exp(0.5 * f32(self.model_log_variance))) if i != 0 else 0.0   # nonzero_mask, base.py:476
+        ab_prev = f32(self.alphas_cumprod_prev)
+        c.sqrt_alpha_bar_prev = float(torch.sqrt(ab_prev))
+        c.sqrt_one_minus_alpha_bar_prev = float(torch.sqrt(1 - ab_prev))
+        return c
+
+    # ---- reference-shaped entry point ------------------------------------------------------------
+    def sample(self, model, shape=None, noise=None, pos=None, cond=None, x_start=None, r_start=None, imgs=None,
+               clip_denoised=True, idx=None, patch_size=64, model_kwargs=None, progress=False, *,
+               x_T: Optional[torch.Tensor] = None,
+               step_noise: Union[None, Sequence[torch.Tensor], Callable[[int], torch.Tensor]] = None):
+        """mode A (idx None): full reverse loop from x_T over an image of `shape`;
+        mode B (idx given, `imgs` = padded patch batch): the single step `idx` (test_brn)."""
+        final = None
+        for final in self.sample_progressive(model, shape, noise, r_start, imgs, idx, x_T=x_T, step_noise=step_noise):
+            pass
+        return final
+
+    def sample_progressive(self, model, shapes, noise, rna, img_patch, idx, *, x_T=None, step_noise=None):
+        device = model.device if hasattr(model, "device") else next(model.parameters()).device
+        if img_patch is not None and idx is None:
+            raise AssertionError("imgs given without idx")                     # base.py:564-565
+        b, c, H, W = shapes
+        # RNG draw order of the reference: the state first (base.py:566) ...
+        img = x_T.to(device) if x_T is not None else torch.randn(tuple(shapes), device=device)
+        ps = noise.shape[2]                                                   # base.py:568
+        P1, P2 = H // ps, W // ps
+        indices = list(range(self.num_timesteps))[::-1] if idx is None else [idx]
+        rna_msk = None
+        if torch.is_tensor(rna):
+            rna_new = rna
+        elif isinstance(rna, (tuple, list)) and len(rna) == 2:
+            rna_new, rna_msk = rna
+        else:
+            r_sz = ps // ((H + ps) // rna[2][1])                              # base.py:594
+            rna_new = sparse_repatch(rna, r_sz)
+        shape_only = torch.empty((b, c, H, W), device="meta")                 # model reads imgs.shape only
+        for k, i in enumerate(indices):
+            t = torch.full((b,), self.timestep_map[i], dtype=torch.int64, device=device)   # _WrappedModel, diffusion.py:140-147
+            x_patches = pad_patchify(img, ps) if img_patch is None else img_patch.to(device).float().contiguous()
+            eps = model(x=x_patches, t=t, rna=rna_new, imgs=shape_only, patch_size=ps, idx=idx).pred
+            nz = None
+            if self.gen_type == "ddpm":
+                if img_patch is not None:
+                    nz = noise                                                # base.py:617
+                elif step_noise is not None:
+                    nz = step_noise(k) if callable(step_noise) else step_noise[k]
+                else:
+                    nz = torch.randn(x_patches.shape, device=device)          # base.py:478
+                nz = nz.to(device).float().contiguous()
+            img = sampler_step(self, i, x_patches, eps, nz, b, P1, P2)
+            if rna_msk is not None:
+                img = img * rna_msk + rna_msk - 1                             # base.py:629-630
+            yield img
+
+
+# ------------------------------------------------------------------------------------------
+# thin wrappers of the C-ABI kernels
+# ------------------------------------------------------------------------------------------
+def pad_patchify(img: torch.Tensor, ps: int, pad_value: float = 0.0) -> torch.Tensor:
+    """F.pad(img, ps/2) + 'b c (p1 h) (p2 w) -> (b p1 p2) c h w' (base.py:606-607)."""
+    img = img.float().contiguous()
+    b, c, H, W = img.shape
+    P1, P2 = H // ps, W // ps
+    out = torch.empty((b * (P1 + 1) * (P2 + 1), c, ps, ps), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.lib().tm_pad_patchify(_lib.ptr(img), _lib.ptr(out), b, c, P1, P2, ps, pad_value,
+                                              _lib.current_stream_ptr()), "tm_pad_patchify")
+    return out
+
+
+def sampler_step(smp: SpacedDiffusionBeatGans, i: int, x_patches, eps, noise, b: int, P1: int, P2: int) -> torch.Tensor:
+    x_patches, eps = x_patches.float().contiguous(), eps.float().contiguous()
+    n, c, ps, _ = x_patches.shape
+    assert n == b * (P1 + 1) * (P2 + 1) and eps.shape[0] == b * P1 * P2
+    out = torch.empty((b, c, P1 * ps, P2 * ps), dtype=torch.float32, device=x_patches.device)
+    coefs = smp.step_coefs(i)
+    mode = 0 if smp.gen_type == "ddpm" else 1
+    nz = noise if (mode == 0 and i != 0) else None
+    with torch.cuda.device(x_patches.device):
+        _lib.check(_lib.lib().tm_sampler_step(C.byref(coefs), _lib.ptr(x_patches), _lib.ptr(eps), _lib.ptr(nz), _lib.ptr(out),
+                                              b, P1, P2, c, ps, mode, _lib.current_stream_ptr()), "tm_sampler_step")
+    return out

@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference model objects for this path.
+
+`BeatGANsUNetModel` keeps the call surface of the reference class of the same name
+(reference model/unet_ours.py:82-426): `model(x=, t=, rna=, imgs=, patch_size=, idx=, pos=, ...)`
+returning `AutoencReturn(pred, pred2, cond)`, `load_state_dict(sd, strict=True)` with the
+reference's key names.  All arithmetic happens in libteramind_hip.so (tm_unet_forward);
+torch is used for device memory and streams only.
+
+`GeneAttnModel` mirrors the attention-map model (reference model/unet_attn.py:143-217).
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+from .config import PathConfig
+from .weights import param_spec
+
+
+class AutoencReturn(NamedTuple):          # reference model/unet_ours.py:429-432
+    pred: torch.Tensor
+    pred2: Optional[torch.Tensor]
+    cond: Optional[torch.Tensor] = None
+
+
+def _tm_config(cfg: PathConfig, vis_only: bool) -> _lib.TmConfig:
+    if len(cfg.ch_mult) != 4 or len(cfg.attn_res) != 1:
+        raise NotImplementedError("ch_mult must have 4 levels and attn_res one resolution")
+    c = _lib.TmConfig()
+    c.patch_size, c.rna_slc, c.n_stain, c.rna_num = cfg.patch_size, cfg.rna_slc, cfg.n_stain, cfg.rna_num
+    c.net_ch, c.embed_ch, c.attn_res = cfg.net_ch, cfg.embed_ch, cfg.attn_res[0]
+    for i, v in enumerate(cfg.ch_mult):
+        c.ch_mult[i] = v
+    c.num_res_blocks, c.vis_only, c.dtype = cfg.num_res_blocks, int(vis_only), 0
+    return c
+
+
+def densify_rna(rna, device):
+    """dense tensor, or the reference's COO triple (dat, crd, ssz) (unet_ours.py:301-306)."""
+    if torch.is_tensor(rna):
+        return rna.to(device=device, dtype=torch.float32).contiguous()
+    dat, crd, ssz = rna
+    t = torch.sparse_coo_tensor(crd.long().to(device), dat.to(device=device, dtype=torch.float32), tuple(ssz))
+    return t.to_dense().contiguous()
+
+
+class _HipModel(torch.nn.Module):
+    """Shared plumbing: owns the tm_model handle and the weight loading contract."""
+    _vis_only = False
+
+    def __init__(self, conf: PathConfig, device="cuda:0"):
+        super().__init__()
+        self.conf = conf
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("teramind_amd models run on a ROCm device only (no CPU fallback)")
+        self._L = _lib.lib()
+        self._h = C.c_void_p(0)
+        cfg = _tm_config(conf, self._vis_only)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.tm_model_create(C.byref(cfg), C.byref(self._h)), "tm_model_create")
+        self._finalized = False
+        self._ws = None
+        # lets `next(model.parameters()).device` (reference diffusion/base.py:562) work
+        self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.device), requires_grad=False)
+
+    # -- weights -------------------------------------------------------------------------
+    def expected_keys(self):
+        n = self._L.tm_model_num_params(self._h)
+        return [self._L.tm_model_param_key(self._h, i).decode() for i in range(n)]
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Reference contract (test_brn.py:140-147): keys as in `model.state_dict()`.
+        strict=False ignores unexpected keys (as the attention driver does, test_attn.py:334);
+        missing keys are always an error because the packed arena needs every tensor."""
+        if self._finalized:
+            raise RuntimeError("weights already loaded (the packed arena is immutable)")
+        want = set(self.expected_keys())
+        unexpected = [k for k in state_dict if k not in want and k != "_anchor"]
+        if unexpected and strict:
+            raise RuntimeError(f"Unexpected key(s) in state_dict: {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        for k, v in state_dict.items():
+            if k not in want:
+                continue
+            hv = v.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            shp = (C.c_int64 * hv.dim())(*hv.shape)
+            _lib.check(self._L.tm_model_load_param(self._h, k.encode(), C.c_void_p(hv.data_ptr()), shp, hv.dim(), 0),
+                       f"tm_model_load_param({k})")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.tm_model_finalize(self._h), "tm_model_finalize")
+        self._finalized = True
+        return self
+
+    def arena(self) -> torch.Tensor:
+        """Zero-copy uint8 tensor view of the packed device weight arena (library-owned
+        memory; used for the one-off RCCL broadcast of rank 0's weights)."""
+        holder = _CudaArray(self._L.tm_model_arena_ptr(self._h), self._L.tm_model_arena_bytes(self._h))
+        return torch.as_tensor(holder, device=self.device)
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.tm_model_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
+
+
+class _CudaArray:
+    """`__cuda_array_interface__` carrier for a raw device pointer."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+class BeatGANsUNetModel(_HipModel):
+    def forward(self, x, t, rna=None, pos=None, y=None, imgs=None, cond=None, noise=None, t_cond=None,
+                idx=None, index=None, do_train=False, patch_size=64, pos_random=None, random=None,
+                want_pred2=False, **kwargs):
+        """Same arguments as the reference forward (unet_ours.py:343-359).  `imgs` is read for
+        its H, W only (:361); `pos`, `idx`, `cond`, `random` are ignored by the `ours` model.
+        `want_pred2=True` additionally runs the original-patch decoder pass (training-only
+        output in the reference; `pred2` is None otherwise)."""
+        if do_train:
+            raise NotImplementedError("training forward (do_train=True) is outside the inference hot path")
+        if not self._finalized:
+            raise RuntimeError("load_state_dict() must be called before forward")
+        if patch_size != self.conf.patch_size:
+            raise ValueError(f"patch_size {patch_size} != configured {self.conf.patch_size}")
+        H, W = imgs.shape[-2:]
+        p1, p2 = H // patch_size + 1, W // patch_size + 1
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        b = t.shape[0]
+        ne, nd = b * p1 * p2, b * (p1 - 1) * (p2 - 1)
+        C_ = self.conf.in_channels
+        if tuple(x.shape) != (ne, C_, patch_size, patch_size):
+            raise ValueError(f"x has shape {tuple(x.shape)}, expected {(ne, C_, patch_size, patch_size)}")
+        rna_d = densify_rna(rna, self.device)
+        gn, zg = self.conf.gn_sz, self.conf.rna_slc * 500
+        if tuple(rna_d.shape) != (ne, gn, gn, zg):
+            raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(ne, gn, gn, zg)}")
+        pred = torch.empty((nd, C_, patch_size, patch_size), dtype=torch.float32, device=self.device)
+        pred2 = torch.empty_like(x) if want_pred2 else None
+        with torch.cuda.device(self.device):
+            need = self._L.tm_workspace_bytes(self._h, b, p1, p2, int(want_pred2))
+            ws = self._workspace(need)
+            _lib.check(self._L.tm_unet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(rna_d), b, p1, p2,
+                                               _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+                                               _lib.current_stream_ptr()), "tm_unet_forward")
+        return AutoencReturn(pred=pred, pred2=pred2, cond=cond)
+
+
+class GeneAttnModel(_HipModel):
+    """Attention-map model: forward(x, t, rna, imgs) -> (attn[4,B,G,G], rna_h[:, :, 1:-1])."""
+    _vis_only = True
+
+    def forward(self, x=None, t=None, rna=None, imgs=None, **kwargs):
+        if not self._finalized:
+            raise RuntimeError("load_state_dict() must be called before forward")
+        rna_d = densify_rna(rna, self.device)
+        B, gn = rna_d.shape[0], self.conf.gn_sz
+        G, zs = self.conf.rna_num, self.conf.rna_slc
+        if tuple(rna_d.shape) != (B, gn, gn, zs * 500):
+            raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(B, gn, gn, zs * 500)}")
+        attn = torch.empty((4, B, G, G), dtype=torch.float32, device=self.device)
+        mid = torch.empty((B, G, zs - 2, gn, gn), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.tm_gene_attn(self._h, _lib.ptr(rna_d), B, _lib.ptr(attn), _lib.ptr(mid),
+                                            C.c_void_p(0), 0, _lib.current_stream_ptr()), "tm_gene_attn")
+        return attn, mid
+
+
+def make_model(conf: PathConfig, device="cuda:0", state_dict=None, vis_only=False):
+    m = (GeneAttnModel if vis_only else BeatGANsUNetModel)(conf, device)
+    if state_dict is not None:
+        m.load_state_dict(state_dict, strict=not vis_only)
+    return m
+
+
+__all__ = ["AutoencReturn", "BeatGANsUNetModel", "GeneAttnModel", "make_model", "param_spec"]

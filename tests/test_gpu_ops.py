@@ -1,0 +1,84 @@
+"""-m gpu: single-kernel parity through the C-ABI (tm_op_*), HIP vs torch CPU fp32.
+Integer-valued operands make the fp32 result exact, so those cases are compared bit for bit
+(catches any indexing / fragment-layout error without a tolerance to hide behind)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_cb8_roundtrip():
+    x = util.rand_int((3, 13, 2, 8, 8), -5, 5, 0).to(DEV)
+    y = util.to_cb8(x)
+    assert y.shape == (3, 2, 2, 8, 8, 8)
+    assert torch.equal(y[:, 1, :, :, :, 5:], torch.zeros_like(y[:, 1, :, :, :, 5:]))      # zero padded slots
+    assert torch.equal(util.from_cb8(y, 13), x)
+
+
+# (N, Cin, Cout, S)
+CONV3_CASES = [(2, 16, 64, 8), (3, 24, 128, 8), (5, 13, 32, 8), (1, 8, 64, 16), (2, 40, 192, 16),
+               (1, 72, 64, 32), (1, 8, 64, 64), (2, 16, 128, 64)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,S", CONV3_CASES)
+@pytest.mark.parametrize("variant", [1, 2])
+def test_conv3_mfma_exact_integers(N, Cin, Cout, S, variant):
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 1)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 2)
+    b = util.rand_int((Cout,), -4, 4, 3)
+    ref = F.conv3d(x, w, b, padding=1)
+    got, raw = util.conv_mfma(x.to(DEV), w, b, 3, variant)
+    assert torch.equal(got.cpu(), ref), util.report("conv3", got, ref)
+    if Cout % 8:
+        assert float(raw[:, -1, ..., Cout % 8:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,S", [(2, 96, 64, 16), (1, 741, 512, 8), (1, 224, 64, 64)])
+def test_conv3_mfma_random(N, Cin, Cout, S):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((N, Cin, 2, S, S), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3, 3), generator=g) / (Cin * 27) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    ref = F.conv3d(x, w, b, padding=1)
+    got, _ = util.conv_mfma(x.to(DEV), w, b, 3)
+    # fp32 accumulation-order noise only: K <= 20007 products of O(1)*O(K^-1/2)
+    assert torch.allclose(got.cpu(), ref, atol=2e-5, rtol=1e-5), util.report("conv3 random", got, ref)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Z,S", [(2, 229, 128, 2, 8), (1, 64, 1792, 2, 16), (3, 13, 32, 2, 8),
+                                            (1, 96, 64, 2, 64), (5, 512, 2048, 2, 8)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_conv1_mfma_exact_integers(N, Cin, Cout, Z, S, variant):
+    x = util.rand_int((N, Cin, Z, S, S), -3, 3, 4)
+    w = util.rand_int((Cout, Cin, 1, 1, 1), -2, 2, 5)
+    b = util.rand_int((Cout,), -4, 4, 6)
+    ref = F.conv3d(x, w, b)
+    got, _ = util.conv_mfma(x.to(DEV), w, b, 1, variant)
+    assert torch.equal(got.cpu(), ref), util.report("conv1", got, ref)
+
+
+DIRECT_CASES = [
+    # N, Cin, Cout, Zin, S, k, pad, silu, up2
+    (3, 2, 64, 2, 64, (1, 3, 3), (0, 1, 1), False, False),     # stem
+    (2, 64, 2, 2, 64, (1, 3, 3), (0, 1, 1), False, False),     # head
+    (3, 229, 229, 4, 4, (3, 3, 3), (0, 1, 1), False, True),    # down_z + upsample
+    (2, 229, 128, 2, 8, (1, 3, 3), (0, 1, 1), True, True),     # pyramid level
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Zin,S,k,pad,silu,up2", DIRECT_CASES)
+def test_conv_direct(N, Cin, Cout, Zin, S, k, pad, silu, up2):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((N, Cin, Zin, S, S), generator=g)
+    w = torch.randn((Cout, Cin) + k, generator=g) / (Cin * k[0] * k[1] * k[2]) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    xi = x * torch.sigmoid(x) if silu else x
+    ref = F.conv3d(xi, w, b, padding=pad)
+    if up2:
+        ref = ref.repeat_interleave(2, -2).repeat_interleave(2, -1)
+    got = util.conv_direct(x.to(DEV), w, b, pad, silu, up2)
+    assert torch.allclose(got.cpu(), ref, atol=2e-5, rtol=1e-5), util.report("direct", got, ref)

@@ -1,0 +1,113 @@
+"""-m gpu: the HIP UNet / sampler / gene-attention path vs the CPU oracle (oracle/teramind_cpu.py)
+on identical hashed weights and seeded synthetic inputs, called through the C-ABI via the
+reference-shaped Python adapter.
+
+Tolerance (fp32): the oracle itself sits 1.5e-6 (max abs, outputs O(1)) from the reference
+on CPU -- pure fp32 re-association noise through ~50 conv layers.  The MFMA kernels use a
+different but equally valid fp32 summation order, so the bound is set at 2e-4 max-abs on
+outputs of std ~0.57 (|max| ~2.5), ~100x above the observed drift."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import teramind_cpu as tc
+from teramind_amd import synth
+from teramind_amd.config import PathConfig
+from teramind_amd.unet import BeatGANsUNetModel, GeneAttnModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ATOL = 2e-4
+
+_MODEL = {}
+
+
+def hip_model():
+    if "m" not in _MODEL:
+        cfg = PathConfig()
+        _MODEL["m"] = BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    return _MODEL["m"]
+
+
+def make_inputs(b, P, seed=0):
+    p = P + 1
+    ne = b * p * p
+    x = synth.normal("x", (ne, 4, 64, 64), seed)
+    rna = synth.gene_counts("rna", (ne, 4, 4, 2000), seed)
+    t = torch.tensor([(137 * (i + 1) + 61 * seed) % 1000 for i in range(b)], dtype=torch.long)
+    return x, t, rna
+
+
+def test_unet_forward_taps_b1_P1(out_dir, tmp_path):
+    """One encoder-grid of 4 patches -> 1 interior patch; every block output compared."""
+    cfg = PathConfig()
+    oc = tc.oracle_config_from(cfg)
+    sd = util.state_dict(cfg)
+    x, t, rna = make_inputs(1, 1)
+    taps = {}
+    with torch.inference_mode():
+        ref, ref2 = tc.unet_forward(sd, oc, x, t, rna, 2, 2, want_pred2=True, taps=taps)
+    os.environ["TM_DEBUG_DIR"] = str(tmp_path)
+    try:
+        out = hip_model()(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64), patch_size=64,
+                          want_pred2=True)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["TM_DEBUG_DIR"]
+    lines, worst = [], 0.0
+    for name, refv in taps.items():
+        f = tmp_path / f"{name}.bin"
+        if not f.exists():
+            continue
+        got = torch.from_numpy(np.fromfile(f, dtype=np.float32)).reshape(refv.shape)
+        lines.append(util.report(name, got, refv))
+        worst = max(worst, (got - refv).abs().max().item() / max(1.0, refv.abs().max().item()))
+    lines.append(util.report("pred", out.pred, ref))
+    lines.append(util.report("pred2", out.pred2, ref2))
+    with open(os.path.join(out_dir, "unet_taps_b1_P1.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert torch.allclose(out.pred.cpu(), ref, atol=ATOL, rtol=0), lines[-2]
+    assert torch.allclose(out.pred2.cpu(), ref2, atol=ATOL, rtol=0), lines[-1]
+    assert worst < 1e-3
+
+
+@pytest.mark.parametrize("b,P", [(2, 1), (1, 2)])
+def test_unet_forward_shapes(b, P):
+    cfg = PathConfig()
+    oc = tc.oracle_config_from(cfg)
+    sd = util.state_dict(cfg)
+    x, t, rna = make_inputs(b, P, seed=3)
+    with torch.inference_mode():
+        ref, _ = tc.unet_forward(sd, oc, x, t, rna, P + 1, P + 1)
+    out = hip_model()(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(b, 4, 64 * P, 64 * P), patch_size=64)
+    assert out.pred2 is None
+    assert torch.allclose(out.pred.cpu(), ref, atol=ATOL, rtol=0), util.report("pred", out.pred, ref)
+
+
+def test_unet_rna_coo_input_equals_dense():
+    x, t, rna = make_inputs(1, 1, seed=5)
+    m = hip_model()
+    kw = dict(x=x.to(DEV), t=t.to(DEV), imgs=torch.zeros(1, 4, 64, 64), patch_size=64)
+    a = m(rna=rna.to(DEV), **kw).pred
+    b = m(rna=synth.dense_to_coo(rna), **kw).pred
+    assert torch.equal(a, b)
+
+
+def test_gene_attention_maps():
+    cfg = PathConfig()
+    oc = tc.oracle_config_from(cfg)
+    sdv = util.state_dict(cfg, vis_only=True)
+    rna = synth.gene_counts("rna_vis", (3, 4, 4, 2000), 1, density=0.05)
+    with torch.inference_mode():
+        ref_a, ref_r = tc.gene_attention_maps(sdv, oc, rna)
+    m = GeneAttnModel(cfg, DEV).load_state_dict(sdv, strict=False)
+    a, r = m(rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64))
+    assert a.shape == (4, 3, 229, 229)
+    assert torch.equal(r.cpu(), ref_r)
+    # softmax probabilities ~1/229: absolute 1e-7 is ~2e-5 relative
+    assert torch.allclose(a.cpu(), ref_a, atol=1e-7, rtol=1e-4), util.report("attn", a, ref_a)
+    assert torch.allclose(a.sum(-1).cpu(), torch.ones(4, 3, 229), atol=1e-5)

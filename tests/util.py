@@ -1,0 +1,77 @@
+"""Shared helpers of the parity tests (HIP path vs oracle/)."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from teramind_amd import _lib
+from teramind_amd.config import PathConfig
+from teramind_amd.weights import hashed_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+_SD = {}
+
+
+def state_dict(cfg: PathConfig = None, seed=0, vis_only=False):
+    cfg = cfg or PathConfig()
+    key = (cfg.name, seed, vis_only)
+    if key not in _SD:
+        _SD[key] = hashed_state_dict(cfg, seed, vis_only)
+    return _SD[key]
+
+
+def rand_int(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+def to_cb8(x):
+    """NCDHW cuda tensor -> CB8 cuda tensor via the library."""
+    N, Cc, Z, H, W = x.shape
+    cb = (Cc + 7) // 8
+    y = torch.empty((N, cb, Z, H, W, 8), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tm_op_to_cb8(_lib.ptr(x.contiguous()), _lib.ptr(y), N, Cc, Z, H, W, _lib.current_stream_ptr()))
+    return y
+
+
+def from_cb8(y, Cc):
+    N, cb, Z, H, W, _ = y.shape
+    x = torch.empty((N, Cc, Z, H, W), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().tm_op_from_cb8(_lib.ptr(y), _lib.ptr(x), N, Cc, Z, H, W, _lib.current_stream_ptr()))
+    return x
+
+
+def conv_mfma(x, w, b, ksize, variant=0):
+    """x NCDHW cuda; w, b host tensors.  Returns NCDHW cuda output of the MFMA conv."""
+    N, Cin, Z, S, _ = x.shape
+    Cout = w.shape[0]
+    xc = to_cb8(x)
+    yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
+    wh, bh = w.contiguous().float(), b.contiguous().float()
+    _lib.check(_lib.lib().tm_op_conv_mfma(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
+                                          N, Cin, Cout, Z, S, ksize, variant, _lib.current_stream_ptr()), "tm_op_conv_mfma")
+    return from_cb8(yc, Cout), yc
+
+
+def conv_direct(x, w, b, pad, silu_in=False, up2=False):
+    N, Cin, Zin, S, _ = x.shape
+    Cout, _, kz, ky, kx = w.shape
+    Zout = Zin + 2 * pad[0] - kz + 1
+    So = 2 * S if up2 else S
+    y = torch.empty((N, Cout, Zout, So, So), dtype=torch.float32, device=x.device)
+    wh, bh = w.contiguous().float(), b.contiguous().float()
+    _lib.check(_lib.lib().tm_op_conv_direct(_lib.ptr(x.contiguous()), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()),
+                                            _lib.ptr(y), N, Cin, Cout, Zin, S, kz, ky, kx, pad[0], pad[1], pad[2],
+                                            int(silu_in), int(up2), _lib.current_stream_ptr()), "tm_op_conv_direct")
+    return y
+
+
+def report(name, got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    d = (got - ref).abs()
+    return (f"{name}: max|d|={d.max().item():.3e} mean|d|={d.mean().item():.3e} "
+            f"ref absmax={ref.abs().max().item():.3e} std={ref.std().item():.3e} "
+            f"nan={int(torch.isnan(got).sum())}")
