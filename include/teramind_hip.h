@@ -137,6 +137,24 @@ int tm_gene_attn(tm_model* m, const void* rna_dense, int B, void* attn_out, void
 
 int tm_model_destroy(tm_model* m);
 
+/* Measurement hooks (bench.py): while enabled, every launch of the dominant kernel
+ * (conv27_mfma, the 3x3x3 implicit-GEMM conv) inside tm_unet_forward is bracketed by two
+ * hipEvents recorded on the forward's stream.  tm_profile_collect synchronises on the last
+ * event, adds up the bracketed durations and the per-launch work, and resets the counters.
+ *   nominal_flops  = 2*Cin*Cout*27*voxels per launch (dense-conv convention; what
+ *                    torch.utils.flop_counter counts for the reference's Conv3d)
+ *   executed_flops = 2/3 of that: the always-zero z tap is not issued (Z == 2)
+ *   alg_bytes      = input + packed weights + output bytes, each counted once per launch */
+typedef struct tm_prof_stats {
+  uint64_t launches;
+  double total_ms;
+  double nominal_flops;
+  double executed_flops;
+  double alg_bytes;
+} tm_prof_stats;
+int tm_profile_enable(tm_model* m, int on);
+int tm_profile_collect(tm_model* m, tm_prof_stats* out);
+
 /* ---- single-operator entry points (parity tests of the individual kernels) -------------
  * Layout "CB8": fp32 [N][ceil(C/8)][Z][H][W][8] (channel blocks of 8, zero padded).      */
 

@@ -28,6 +28,11 @@ class TmStepCoefs(C.Structure):
                 ("sqrt_one_minus_alpha_bar_prev", c_float)]
 
 
+class TmProfStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("nominal_flops", C.c_double),
+                ("executed_flops", C.c_double), ("alg_bytes", C.c_double)]
+
+
 # name -> (restype, argtypes); mirrors include/teramind_hip.h one to one
 SIGNATURES = {
     "tm_version": (c_int, []),
@@ -48,6 +53,8 @@ SIGNATURES = {
     "tm_gene_attn_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "tm_gene_attn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tm_model_destroy": (c_int, [c_void_p]),
+    "tm_profile_enable": (c_int, [c_void_p, c_int]),
+    "tm_profile_collect": (c_int, [c_void_p, C.POINTER(TmProfStats)]),
     "tm_op_to_cb8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "tm_op_from_cb8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "tm_op_conv_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

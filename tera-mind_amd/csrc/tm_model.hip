@@ -90,6 +90,11 @@ struct tm_model {
   GeneW gene;
   DirectW downz, pyr[3], stem, head;
   const float* out_norm = nullptr;
+  // measurement hooks (tm_profile_*)
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
+  double prof_nominal = 0, prof_bytes = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -473,8 +478,31 @@ extern "C" int tm_model_finalize(tm_model* m) {
 extern "C" size_t tm_model_arena_bytes(const tm_model* m) { return m ? m->arena_floats * sizeof(float) : 0; }
 extern "C" void* tm_model_arena_ptr(tm_model* m) { return m ? (void*)m->arena : nullptr; }
 
+extern "C" int tm_profile_enable(tm_model* m, int on) {
+  if (!m) return fail(TM_ERR_ARG, "null model");
+  m->prof_on = on != 0;
+  return TM_OK;
+}
+extern "C" int tm_profile_collect(tm_model* m, tm_prof_stats* out) {
+  if (!m || !out) return fail(TM_ERR_ARG, "null argument");
+  memset(out, 0, sizeof(*out));
+  if (m->prof_used) HIP_TRY(hipEventSynchronize(m->prof_ev[m->prof_used - 1].second));
+  for (size_t i = 0; i < m->prof_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, m->prof_ev[i].first, m->prof_ev[i].second));
+    out->total_ms += ms;
+  }
+  out->launches = m->prof_used;
+  out->nominal_flops = m->prof_nominal;
+  out->executed_flops = m->prof_nominal * (18.0 / 27.0);
+  out->alg_bytes = m->prof_bytes;
+  m->prof_used = 0; m->prof_nominal = 0; m->prof_bytes = 0;
+  return TM_OK;
+}
+
 extern "C" int tm_model_destroy(tm_model* m) {
   if (!m) return TM_OK;
+  for (auto& e : m->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (m->arena) (void)hipFree(m->arena);
   delete m;
   return TM_OK;
@@ -533,11 +561,29 @@ static void dump_tv(Ctx& cx, const std::string& name, const TV& t) {
   (void)hipFree(dev);
 }
 
-static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags) {
+static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags,
+                     int cin_real = 0) {
   if (cx.dry) return;
   ConvLaunch L;
   L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
+  tm_model* m = cx.m;
+  const bool prof = m->prof_on && w.taps == 27;
+  if (prof) {
+    if (m->prof_used == m->prof_ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { cx.check(hipErrorOutOfMemory); return; }
+      m->prof_ev.emplace_back(a, b);
+    }
+    cx.check(hipEventRecord(m->prof_ev[m->prof_used].first, cx.s));
+  }
   cx.check(launch_conv_mfma(L, cx.s));
+  if (prof) {
+    cx.check(hipEventRecord(m->prof_ev[m->prof_used].second, cx.s));
+    m->prof_used++;
+    const double vox = (double)x.N * x.Z * x.H * x.W;
+    m->prof_nominal += 2.0 * (cin_real ? cin_real : x.C) * w.Cout * 27.0 * vox;
+    m->prof_bytes += 4.0 * (vox * x.Cb * 8 + (double)w.ntile * w.Cbi * 27 * 512 + vox * y.Cb * 8);
+  }
 }
 
 // ResBlock._forward (model/MBAblocks.py:237-299)
@@ -550,7 +596,9 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   int cin_pad = w.cbi * 8;
   TV A = cx.tensor(N, cin_pad, Z, S_out);
   TV raw;
-  const bool need_raw = w.has_skip || mode != RS_SAME;
+  // the residual / skip-conv input is the CONCATENATED (and resampled) x, MBAblocks.py:252-258,297:
+  // it equals a stored tensor only for a single plain source
+  const bool need_raw = w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage;
   if (need_raw) raw = cx.tensor(N, cin_pad, Z, S_out);
   if (!cx.dry) {
     PrepLaunch P;
@@ -566,7 +614,7 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     cx.check(launch_prep(P, cx.s));
   }
   TV H1 = cx.tensor(N, w.cout, Z, S_out);
-  run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0);
+  run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
   TV A2 = cx.tensor(N, w.cout, Z, S_out);
   if (!cx.dry) {
     PrepLaunch P;
@@ -582,7 +630,7 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   if (w.has_skip) {
     run_conv(cx, raw, w.skip, out, nullptr, nullptr, 0);
     run_conv(cx, A2, w.c2, out, &out, nullptr, 0);
-  } else if (mode != RS_SAME) {
+  } else if (need_raw) {
     run_conv(cx, A2, w.c2, out, &raw, nullptr, 0);
   } else {
     run_conv(cx, A2, w.c2, out, &src[0].t, nullptr, 0);

@@ -98,6 +98,16 @@ class _HipModel(torch.nn.Module):
         holder = _CudaArray(self._L.tm_model_arena_ptr(self._h), self._L.tm_model_arena_bytes(self._h))
         return torch.as_tensor(holder, device=self.device)
 
+    def profile(self, on: bool):
+        """Bracket every conv27_mfma launch with hipEvents (measurement hook, bench.py)."""
+        _lib.check(self._L.tm_profile_enable(self._h, int(on)), "tm_profile_enable")
+
+    def profile_collect(self) -> dict:
+        st = _lib.TmProfStats()
+        _lib.check(self._L.tm_profile_collect(self._h, C.byref(st)), "tm_profile_collect")
+        return {"launches": int(st.launches), "total_ms": st.total_ms, "nominal_flops": st.nominal_flops,
+                "executed_flops": st.executed_flops, "alg_bytes": st.alg_bytes}
+
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
