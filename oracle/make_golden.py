@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- mints tests/golden/* from the REAL reference (container only).
+
+    python oracle/make_golden.py            # needs /root/reference; CPU; ~2 min
+
+Fixtures are data: seeded inputs are regenerated at test time by teramind_amd.synth /
+teramind_amd.weights (never stored), only the reference's outputs (or digests of them) are
+written.  The reference is imported through oracle/ref_harness.py (import stubs only; its
+sources are never copied).  Random draws inside the reference's sampler are redirected to the
+seeded synth generator for the duration of one call so that the trajectories are reproducible
+from (tag, seed) alone.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import teramind_amd  # noqa: E402,F401
+from oracle import ref_harness as rh  # noqa: E402
+from teramind_amd import synth  # noqa: E402
+from teramind_amd.config import PathConfig  # noqa: E402
+from teramind_amd.weights import hashed_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def digest(t: torch.Tensor, n=64):
+    f = t.detach().float().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return {"shape": list(t.shape), "mean": float(f.double().mean()), "absmax": float(f.abs().max()),
+            "l2": float(f.double().pow(2).sum().sqrt()), "samples": f[idx].tolist()}
+
+
+@contextlib.contextmanager
+def seeded_randn(tag):
+    """Route torch.randn / randn_like to synth.normal(f'{tag}/{k}') for the k-th draw."""
+    cnt = {"k": 0}
+    o_randn, o_like = torch.randn, torch.randn_like
+
+    def fake_randn(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        t = synth.normal(f"{tag}/{cnt['k']}", shape, 0)
+        cnt["k"] += 1
+        return t
+
+    def fake_like(x, **kw):
+        return fake_randn(tuple(x.shape))
+
+    torch.randn, torch.randn_like = fake_randn, fake_like
+    try:
+        yield cnt
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def integer_paths(ns):
+    st = ns.diffusion.diffusion.space_timesteps
+    g = {"space_timesteps": {}}
+    for key, (T, sc) in {"ddim15": (1000, "ddim15"), "ddim50": (1000, "ddim50"), "ddim100": (1000, "ddim100"),
+                         "list50": (1000, [50]), "list15": (1000, [15]), "list3": (1000, [3]), "list1000": (1000, [1000]),
+                         "sections_300": (300, "10,15,20")}.items():
+        g["space_timesteps"][key] = {"T": T, "section_counts": sc, "steps": sorted(st(T, sc))}
+    # timestep maps of the spaced samplers
+    g["timestep_map"] = {}
+    for T, gen in [(15, "ddim"), (50, "ddim"), (50, "ddpm"), (3, "ddpm")]:
+        s = rh.make_sampler(rh.make_conf(), T, gen)
+        g["timestep_map"][f"{gen}{T}"] = list(map(int, s.timestep_map))
+    # sparse_repatch (in place in the reference -> pass clones)
+    s = rh.make_sampler(rh.make_conf(), 15, "ddim")
+    gen = torch.Generator().manual_seed(3)
+    ssz = torch.Size([2, 8, 12, 2000])
+    nnz = 200
+    crd = torch.stack([torch.randint(0, ssz[d], (nnz,), generator=gen) for d in range(4)])
+    dat = torch.arange(nnz).float()
+    d2, c2, s2 = s.sparse_repatch((dat.clone(), crd.clone(), ssz), 4)
+    g["sparse_repatch"] = {"ssz": list(ssz), "sz": 4, "crd_in": crd.tolist(), "crd_out": c2.tolist(), "ssz_out": list(s2)}
+    return g
+
+
+def tile_driver_paths(ns):
+    """a23 / a24: run the reference's own Tester._run_batch and MBADataset_tst._pad_im on stubs."""
+    import importlib
+    sys.modules.setdefault("PIL", types.ModuleType("PIL"))
+    if not hasattr(sys.modules["PIL"], "Image"):
+        sys.modules["PIL"].Image = types.SimpleNamespace()
+        sys.modules["PIL.Image"] = sys.modules["PIL"].Image
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        tb = importlib.import_module("test_brn")
+        ds = importlib.import_module("utils.MBADataset_tst")
+    # ---- lcg + gene tile names ----
+    out["lcg"] = {str(k): int(ds.lcg(k)) for k in (0, 1, 415, 416, 417, 286 * 416 + 413, 2 ** 20)}
+    from pathlib import Path
+    out["gn_sublst"] = [p.name for p in tb.gn_sublst(Path("g"), hst=256, wst=512, hnm=2, wnm=3)]
+    # ---- initial padded noise tile (step 0) ----
+    d = ds.MBADataset_tst.__new__(ds.MBADataset_tst)
+    d.size, d.pad, d.chn, d.gblk, d.wid = 256, 32, 100, 16, 52 * 8
+    d.gsz = (256 + 64) // 16
+    d.hst, d.wst = 1, 2
+    d.hed, d.wed = d.hst + 3, d.wst + 3
+    d.idir = None
+    tiles = {}
+    for roi in ([256, 512, 512, 768], [512, 768, 768, 1024], [768, 1024, 1024, 1280]):
+        t, stp = d._pad_im(np.array(roi), 0)
+        assert stp == 0
+        tiles["_".join(map(str, roi))] = digest(t, 48) | {"n_minus1": int((t == -1).sum())}
+    out["pad_im_step0"] = {"hst": d.hst, "wst": d.wst, "hnm": 3, "wnm": 3, "tiles": tiles}
+    # ---- Tester._run_batch index maps (z-chunk, patchify, regroup, fp16) ----
+    cap = {}
+
+    class StubSampler:
+        def sample(self, **kw):
+            cap.update({k: v for k, v in kw.items() if k != "model"})
+            n = kw["shape"][0]
+            return (torch.arange(n * 4 * 256 * 256, dtype=torch.float32).reshape(n, 4, 256, 256) % 2039) / 64.0
+
+    saved = {}
+    tb.zarr.save_array = lambda p, a: saved.__setitem__(str(p), a)
+    t = tb.Tester.__new__(tb.Tester)
+    t.gpu_id = "cpu"
+    t.conf = types.SimpleNamespace(patch_size=64, gn_sz=4)
+    t.z_size, t.total_slc, t.n_stn, t.epochs = 4, 50, 2, 15
+    t.sampler, t.model = StubSampler(), None
+    b = 1
+    tile = torch.arange(b * 320 * 320 * 100, dtype=torch.float32).reshape(b, 320, 320, 100)
+    # sparse gene tile [b, 20, 20, 26000]: value = flat index + 1 at a few hundred positions
+    gen = torch.Generator().manual_seed(9)
+    ssz = torch.Size([b, 20, 20, 26000])
+    nnz = 4000
+    crd = torch.stack([torch.randint(0, ssz[k], (nnz,), generator=gen) for k in range(4)])
+    crd = torch.unique(crd, dim=1)
+    dat = (crd[1] * 20 * 26000 + crd[2] * 26000 + crd[3] + 1).float()
+    roi = torch.tensor([[256, 512, 512, 768]])
+    stp = torch.tensor([3])
+    from pathlib import Path as _P
+    t._run_batch((tile, roi, dat, crd, ssz, stp), 3, _P("o"))
+    xin, rin = cap["imgs"], cap["r_start"]
+    out["run_batch"] = {
+        "idx": int(cap["idx"]), "shape": [int(v) for v in cap["shape"]], "patch_size": int(cap["patch_size"]),
+        "imgs_shape": list(xin.shape), "rna_shape": list(rin.shape),
+        "imgs_digest": digest(xin, 97), "imgs_sum": float(xin.double().sum()),
+        # every patch's [c=1][y=5][x=7] element identifies the (chunk, patch, channel, pixel) -> source index map
+        "imgs_probe": xin[:, 1, 5, 7].long().tolist(),
+        "rna_nonzero": int((rin != 0).sum()), "rna_sum": float(rin.double().sum()),
+        "rna_probe": [[int(v) for v in rin[n].nonzero()[:3].reshape(-1).tolist()] + [float(rin[n].max())]
+                      for n in (0, 7, 24 * 25 + 12, 624)],
+        "saved_key": list(saved.keys())[0], "saved_dtype": str(list(saved.values())[0].dtype),
+        "saved_shape": list(list(saved.values())[0].shape),
+        "saved_digest": digest(torch.from_numpy(list(saved.values())[0].astype(np.float32)), 97),
+    }
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = rh.load()
+    torch.manual_seed(0)
+    cfg = PathConfig()
+
+    # ---------------- G1 integer paths + a23/a24 ----------------
+    g1 = integer_paths(ns)
+    g1.update(tile_driver_paths(ns))
+    json.dump(g1, open(os.path.join(OUT, "integer_paths.json"), "w"))
+    print("G1 integer paths written")
+
+    # ---------------- G2 coefficient tables ----------------
+    tabs = {}
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+             "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+    for T, gen in [(15, "ddim"), (50, "ddim"), (50, "ddpm"), (1000, "ddpm")]:
+        s = rh.make_sampler(rh.make_conf(), T, gen)
+        for n in names:
+            tabs[f"{gen}{T}/{n}"] = np.asarray(getattr(s, n), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "tables.npz"), **tabs)
+    print("G2 tables written")
+
+    # ---------------- G4 full-config UNet outputs ----------------
+    conf = rh.make_conf()
+    model = rh.make_model(conf)
+    sd = hashed_state_dict(cfg, 0)
+    model.load_state_dict(sd, strict=True)
+    hooks, acts = [], {}
+    for name, mod in model.named_modules():
+        if name.count(".") == 1 and name.split(".")[0] in ("input_blocks", "output_blocks"):
+            hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: acts.setdefault(name, []).append(o)))
+    unet = {}
+    for b, P, seed in [(1, 1, 0), (1, 2, 3)]:
+        p = P + 1
+        ne = b * p * p
+        x = synth.normal("x", (ne, 4, 64, 64), seed)
+        rna = synth.gene_counts("rna", (ne, 4, 4, 2000), seed)
+        t = torch.tensor([(137 * (i + 1) + 61 * seed) % 1000 for i in range(b)], dtype=torch.long)
+        acts.clear()
+        with torch.inference_mode():
+            o = model(x=x, t=t, rna=rna, imgs=torch.zeros(b, 4, 64 * P, 64 * P), patch_size=64)
+        tag = f"b{b}_P{P}_s{seed}"
+        unet[f"{tag}/pred"] = o.pred.numpy()
+        if P == 1:
+            unet[f"{tag}/pred2"] = o.pred2.numpy()
+        dg = {}
+        for name, lst in acts.items():
+            # output_blocks run twice (collage pass first)
+            dg[name] = digest(lst[0], 32)
+        unet[f"{tag}/digests"] = np.frombuffer(json.dumps(dg).encode(), dtype=np.uint8)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, "unet_full.npz"), **unet)
+    print("G4 UNet outputs written")
+
+    # ---------------- G5 sampler trajectories ----------------
+    traj = {}
+    rna4 = synth.gene_counts("traj/rna", (4, 4, 4, 2000), 0)
+    for gen, T in [("ddpm", 3), ("ddim", 15)]:
+        s = rh.make_sampler(conf, T, gen)
+        with seeded_randn(f"traj/{gen}{T}") as cnt, torch.inference_mode():
+            out = quiet(s.sample, model=model, shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), r_start=rna4,
+                        patch_size=64)
+        traj[f"modeA_{gen}{T}/final"] = out.numpy()
+        traj[f"modeA_{gen}{T}/ndraws"] = np.array([cnt["k"]])
+        print(f"G5 mode A {gen}{T}: {cnt['k']} randn draws")
+    s = rh.make_sampler(conf, 15, "ddim")
+    xp = synth.normal("traj/modeB/x", (4, 4, 64, 64), 0) * 0.8
+    with torch.inference_mode():
+        out = quiet(s.sample, model=model, shape=(1, 4, 64, 64), imgs=xp, noise=xp, r_start=rna4, patch_size=64, idx=7,
+                    model_kwargs=None)
+    traj["modeB_ddim15_idx7/out"] = out.numpy()
+    traj["modeB_ddim15_idx7/out_half"] = out.half().numpy()
+    np.savez_compressed(os.path.join(OUT, "sampler_traj.npz"), **traj)
+    print("G5 trajectories written")
+
+    # ---------------- G6 attention maps + att@rna products ----------------
+    confv = rh.make_conf(method="ours_vis")
+    mv = rh.make_model(confv)
+    sdv = hashed_state_dict(cfg, 0, vis_only=True)
+    mv.load_state_dict(sdv, strict=False)
+    rna = synth.gene_counts("rna_vis", (2, 4, 4, 2000), 1, density=0.05)
+    with torch.inference_mode():
+        attn, mid = mv.forward(x=None, t=None, rna=rna, imgs=torch.zeros(1, 4, 64, 64))
+    glst = [75, 191]                      # GLUT pathway gene indices
+    g6 = {"attn_b0": attn[:, 0].numpy(), "attn_b1_digest": np.frombuffer(json.dumps(digest(attn[:, 1], 128)).encode(), dtype=np.uint8),
+          "attn_glst": attn[:, :, glst][:, :, :, glst].numpy(), "mid": mid.numpy()}
+    np.savez_compressed(os.path.join(OUT, "attn_maps.npz"), **g6)
+    print("G6 attention maps written")
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""Tiled whole-brain / ROI sweep with the diffusion state resident in device memory.
+
+Replaces the data plane of the reference inference driver (test_brn.py:124-295 `Tester`,
+utils/MBADataset_tst.py:91-123 `_pad_im`): there every diffusion step writes each 256x256x100
+tile to a zarr .zip as fp16 and the next step re-reads the 3x3 neighbourhood of every tile to
+assemble its 32-px halo; ranks are synchronised with three barriers per step around the
+filesystem.  Here:
+
+  * each rank owns a contiguous block of tile rows (tiles.row_block_partition) and keeps the
+    state of its rows, plus a 32-px frame, as one canvas tensor [C, rows*256+64, wnm*256+64];
+  * a step reads tile windows straight out of the canvas (the halo is already in place),
+    runs the reference-shaped `sampler.sample(..., idx=T-epoch-1)` per tile batch and writes
+    the centre of every tile into the second canvas, rounded through fp16 exactly where the
+    reference casts (`out.half()`, test_brn.py:222);
+  * after the step the top / bottom 32-px strips are exchanged with ranks r-1 / r+1
+    (torch.distributed P2P: RCCL send/recv over xGMI on GPUs, gloo on CPU) -- this single
+    exchange is both the halo "all-gather" and the step barrier;
+  * outside the ROI the frame stays at -1 (MBADataset_tst.py:95).
+
+The compute is injected (`sampler`, `model`) so that the distributed / indexing logic is
+testable on CPU with gloo and a stand-in model; on a GPU box they are
+teramind_amd.diffusion.SpacedDiffusionBeatGans and teramind_amd.unet.BeatGANsUNetModel.
+"""
+from typing import Callable, Optional
+
+import torch
+
+from . import tiles
+from .config import PathConfig, Z_PAD
+
+PAD = 32                     # halo = patch_size // 2 (test_brn.py:285 `pad=conf.patch_size // 2`)
+
+
+class TileSweep:
+    def __init__(self, conf: PathConfig, sampler, model, gene_provider: Callable[[int, int], torch.Tensor],
+                 hst: int = 256, wst: int = 256, hnm: int = 32, wnm: int = 32, total_epochs: int = 15,
+                 total_slc: int = 50, device="cpu", rank: int = 0, world: int = 1, batch_tiles: int = 1,
+                 group=None, init: str = "reference", noise_provider: Optional[Callable] = None):
+        """hst/wst/hnm/wnm/total_epochs mirror the test_brn CLI (test_brn.py:302-334).
+        gene_provider(row, col) -> dense [20, 20, (total_slc + 2*zpad) * 500] gene tile (already
+        block-summed and z-padded like MBADataset_tst._getgene/_pad_gn) for ABSOLUTE tile
+        (row, col).  init: 'reference' = LCG-seeded CPU randn per tile; 'device' = torch.randn
+        on the device seeded per tile (fast, not the reference's stream)."""
+        if conf.rna_slc not in (4, 8, 16):
+            raise NotImplementedError("TileSweep implements the z-chunked configs (rna_slc in 4, 8, 16)")
+        self.conf, self.sampler, self.model, self.gene = conf, sampler, model, gene_provider
+        self.hnm, self.wnm, self.T = hnm, wnm, total_epochs
+        self.row0, self.col0 = hst // tiles.TILE, wst // tiles.TILE          # MBADataset_tst.py:33
+        self.total_slc, self.n_stain = total_slc, conf.n_stain
+        self.chn = total_slc * conf.n_stain
+        self.dev, self.rank, self.world, self.group = torch.device(device), rank, world, group
+        self.batch_tiles, self.init, self.noise_provider = batch_tiles, init, noise_provider
+        self.r0, self.r1 = tiles.row_block_partition(hnm, world)[rank]
+        self.nrows = self.r1 - self.r0
+        H = self.nrows * tiles.TILE + 2 * PAD
+        W = wnm * tiles.TILE + 2 * PAD
+        # two canvases (read: step e, write: step e+1); frame initialised to -1
+        self.cur = torch.full((self.chn, H, W), -1.0, dtype=torch.float32, device=self.dev)
+        self.nxt = torch.full((self.chn, H, W), -1.0, dtype=torch.float32, device=self.dev)
+        self.epoch = 0
+        self._fill_initial_noise()
+        self._exchange(self.cur)
+
+    # ---- state ------------------------------------------------------------------------------
+    def _centre(self, canvas, lr: int, c: int):
+        y, x = PAD + lr * tiles.TILE, PAD + c * tiles.TILE
+        return canvas[:, y:y + tiles.TILE, x:x + tiles.TILE]
+
+    def _fill_initial_noise(self):
+        for lr in range(self.nrows):
+            for c in range(self.wnm):
+                row, col = self.row0 + self.r0 + lr, self.col0 + c
+                if self.init == "reference":
+                    t = tiles.initial_noise_tile(row, col, self.chn)
+                else:
+                    g = torch.Generator(device=self.dev)
+                    g.manual_seed(tiles.tile_noise_seed(row, col))
+                    t = torch.randn((tiles.TILE, tiles.TILE, self.chn), generator=g, device=self.dev)
+                self._centre(self.cur, lr, c).copy_(t.permute(2, 0, 1))
+
+    def _exchange(self, canvas):
+        """32-px strips to / from the neighbouring ranks (full canvas width: corners included)."""
+        if self.world == 1 or self.nrows == 0:
+            return
+        import torch.distributed as dist
+        ops, bufs = [], []
+        H = canvas.shape[1]
+        up, down = self.rank - 1, self.rank + 1
+        if up >= 0:
+            send = canvas[:, PAD:2 * PAD, :].contiguous()
+            recv = torch.empty_like(send)
+            ops += [dist.P2POp(dist.isend, send, up, self.group), dist.P2POp(dist.irecv, recv, up, self.group)]
+            bufs.append((recv, slice(0, PAD)))
+        if down < self.world:
+            send = canvas[:, H - 2 * PAD:H - PAD, :].contiguous()
+            recv = torch.empty_like(send)
+            ops += [dist.P2POp(dist.isend, send, down, self.group), dist.P2POp(dist.irecv, recv, down, self.group)]
+            bufs.append((recv, slice(H - PAD, H)))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for recv, sl in bufs:
+            canvas[:, sl, :].copy_(recv)
+
+    # ---- one diffusion step over the rank's tiles ----------------------------------------------
+    def _window(self, lr: int, c: int) -> torch.Tensor:
+        y, x = lr * tiles.TILE, c * tiles.TILE
+        return self.cur[:, y:y + tiles.TILE + 2 * PAD, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)     # 'h w c'
+
+    def run_batch(self, tile_list, epoch: int):
+        """Tester._run_batch (test_brn.py:174-226) for a list of (local_row, col) tiles."""
+        conf = self.conf
+        tile_hwc = torch.stack([self._window(lr, c) for lr, c in tile_list])
+        rna_hwc = torch.stack([self.gene(self.row0 + self.r0 + lr, self.col0 + c).to(self.dev) for lr, c in tile_list])
+        x, rna, shape = tiles.run_batch_inputs(tile_hwc, rna_hwc, conf.patch_size, conf.gn_sz, self.total_slc, conf.rna_slc)
+        out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
+                                  patch_size=conf.patch_size, idx=self.T - epoch - 1, model_kwargs=None)
+        out = tiles.regroup_output(out, len(tile_list), self.n_stain)
+        out = out.half().float()                                              # test_brn.py:222
+        for k, (lr, c) in enumerate(tile_list):
+            self._centre(self.nxt, lr, c).copy_(out[k])
+
+    def step(self):
+        todo = [(lr, c) for lr in range(self.nrows) for c in range(self.wnm)]
+        for i in range(0, len(todo), self.batch_tiles):
+            self.run_batch(todo[i:i + self.batch_tiles], self.epoch)
+        self._exchange(self.nxt)
+        self.cur, self.nxt = self.nxt, self.cur
+        self.epoch += 1
+
+    def test(self):
+        """Tester.test (test_brn.py:232-273): one diffusion step per epoch."""
+        while self.epoch < self.T:
+            self.step()
+        return self.local_state()
+
+    # ---- results -------------------------------------------------------------------------------
+    def local_state(self) -> torch.Tensor:
+        """[C, nrows*256, wnm*256] state of this rank's rows (without the frame)."""
+        return self.cur[:, PAD:self.cur.shape[1] - PAD, PAD:self.cur.shape[2] - PAD]
+
+    def tile(self, lr: int, c: int) -> torch.Tensor:
+        """[C, 256, 256] -- what the reference stores as '{name}.zip' (fp16) after each step."""
+        return self._centre(self.cur, lr, c)
+
+
+def synthetic_gene_provider(conf: PathConfig, total_slc: int = 50, density: float = 0.02, device="cpu"):
+    """Config-3 synthetic genes: a [20, 20, 26000] tile seeded by the tile
+    index; zero in the z-padding slices like MBADataset_tst._getgene."""
+    from . import synth
+    zpad = Z_PAD[conf.rna_slc]
+    cells = (tiles.TILE + 2 * PAD) // (conf.patch_size // conf.gn_sz)
+
+    def provider(row: int, col: int) -> torch.Tensor:
+        core = synth.gene_counts(f"gene/{row}/{col}", (cells, cells, total_slc * tiles.GENES), 0, density)
+        if zpad:
+            z = torch.zeros((cells, cells, zpad * tiles.GENES))
+            core = torch.cat((z, core, z), dim=-1)
+        return core.to(device)
+    return provider
