@@ -1,0 +1,100 @@
+"""-m gpu: the HIP path against the committed golden vectors that oracle/make_golden.py minted
+from the REAL reference (tests/golden/*.npz) -- reference outputs, not oracle outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from teramind_amd import synth
+from teramind_amd.config import PathConfig
+from teramind_amd.diffusion import SpacedDiffusionBeatGans
+from teramind_amd.unet import BeatGANsUNetModel, GeneAttnModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = util.GOLDEN
+_M = {}
+
+
+def model():
+    if "m" not in _M:
+        cfg = PathConfig()
+        _M["m"] = BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    return _M["m"]
+
+
+@pytest.mark.parametrize("b,P,seed", [(1, 1, 0), (1, 2, 3)])
+def test_unet_vs_reference_outputs(b, P, seed):
+    gold = np.load(os.path.join(G, "unet_full.npz"))
+    p = P + 1
+    ne = b * p * p
+    x = synth.normal("x", (ne, 4, 64, 64), seed)
+    rna = synth.gene_counts("rna", (ne, 4, 4, 2000), seed)
+    t = torch.tensor([(137 * (i + 1) + 61 * seed) % 1000 for i in range(b)], dtype=torch.long)
+    out = model()(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(b, 4, 64 * P, 64 * P), patch_size=64,
+                  want_pred2=(P == 1))
+    tag = f"b{b}_P{P}_s{seed}"
+    ref = torch.from_numpy(gold[f"{tag}/pred"])
+    assert torch.allclose(out.pred.cpu(), ref, atol=2e-4, rtol=0), util.report("pred vs reference", out.pred, ref)
+    if P == 1:
+        ref2 = torch.from_numpy(gold[f"{tag}/pred2"])
+        assert torch.allclose(out.pred2.cpu(), ref2, atol=2e-4, rtol=0), util.report("pred2 vs reference", out.pred2, ref2)
+
+
+def test_sample_mode_A_trajectories_vs_reference():
+    """sampler.sample(...) with the reference signature, mode A (gen_sample call shape), fixed noise."""
+    gold = np.load(os.path.join(G, "sampler_traj.npz"))
+    rna = synth.gene_counts("traj/rna", (4, 4, 4, 2000), 0).to(DEV)
+    # DDPM, T=3: draws 0 (x_T), 1 (placeholder, unused), 2.. (per-step noise)
+    smp = SpacedDiffusionBeatGans(3, "ddpm")
+    xT = synth.normal("traj/ddpm3/0", (1, 4, 64, 64), 0)
+    noises = [synth.normal(f"traj/ddpm3/{k + 2}", (4, 4, 64, 64), 0) for k in range(3)]
+    out = smp.sample(model=model(), shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), r_start=rna, patch_size=64,
+                     x_T=xT, step_noise=noises)
+    ref = torch.from_numpy(gold["modeA_ddpm3/final"])
+    # t=999 of a 3-step schedule amplifies forward noise by sqrt(1/abar - 1) ~ 158 before the clamp
+    assert torch.allclose(out.cpu(), ref, atol=5e-3, rtol=0), util.report("ddpm3", out, ref)
+    smp = SpacedDiffusionBeatGans(15, "ddim")
+    xT = synth.normal("traj/ddim15/0", (1, 4, 64, 64), 0)
+    out = smp.sample(model=model(), shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), r_start=rna, patch_size=64, x_T=xT)
+    ref = torch.from_numpy(gold["modeA_ddim15/final"])
+    assert torch.allclose(out.cpu(), ref, atol=2e-3, rtol=0), util.report("ddim15", out, ref)
+
+
+def test_sample_mode_B_single_step_vs_reference():
+    """test_brn call shape: imgs = noise = padded patch batch, idx given, DDIM-15, then the fp16 cast."""
+    gold = np.load(os.path.join(G, "sampler_traj.npz"))
+    rna = synth.gene_counts("traj/rna", (4, 4, 4, 2000), 0).to(DEV)
+    xp = (synth.normal("traj/modeB/x", (4, 4, 64, 64), 0) * 0.8).to(DEV)
+    smp = SpacedDiffusionBeatGans(15, "ddim")
+    out = smp.sample(model=model(), shape=(1, 4, 64, 64), imgs=xp, noise=xp, r_start=rna, patch_size=64, idx=7, model_kwargs=None)
+    ref = torch.from_numpy(gold["modeB_ddim15_idx7/out"])
+    assert torch.allclose(out.cpu(), ref, atol=2e-4, rtol=0), util.report("modeB", out, ref)
+    half = torch.from_numpy(gold["modeB_ddim15_idx7/out_half"].astype(np.float32))
+    assert (out.half().float().cpu() - half).abs().max() <= 2e-3
+
+
+def test_sample_accepts_sparse_coo_rna_like_gen_sample():
+    """mode A with the COO triple over the padded image grid (sparse_repatch path, base.py:594-595)."""
+    rna_p = synth.gene_counts("traj/rna", (4, 4, 4, 2000), 0)                    # per padded patch (b p1 p2) h w g
+    grid = rna_p.reshape(1, 2, 2, 4, 4, 2000).permute(0, 1, 3, 2, 4, 5).reshape(1, 8, 8, 2000)
+    smp = SpacedDiffusionBeatGans(3, "ddim")
+    xT = synth.normal("coo/xT", (1, 4, 64, 64), 0)
+    kw = dict(model=model(), shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), patch_size=64, x_T=xT)
+    a = smp.sample(r_start=rna_p.to(DEV), **kw)
+    b = smp.sample(r_start=synth.dense_to_coo(grid), **kw)
+    assert torch.equal(a, b)
+
+
+def test_attention_maps_vs_reference():
+    gold = np.load(os.path.join(G, "attn_maps.npz"))
+    cfg = PathConfig()
+    m = GeneAttnModel(cfg, DEV).load_state_dict(util.state_dict(cfg, vis_only=True), strict=False)
+    rna = synth.gene_counts("rna_vis", (2, 4, 4, 2000), 1, density=0.05)
+    attn, mid = m(rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64))
+    assert torch.allclose(attn[:, 0].cpu(), torch.from_numpy(gold["attn_b0"]), atol=1e-7, rtol=1e-4)
+    assert torch.equal(mid.cpu(), torch.from_numpy(gold["mid"]))
+    g = attn[:, :, [75, 191]][:, :, :, [75, 191]].cpu()
+    assert torch.allclose(g, torch.from_numpy(gold["attn_glst"]), atol=1e-7, rtol=1e-4)
