@@ -162,12 +162,15 @@ int tm_profile_collect(tm_model* m, tm_prof_stats* out);
 int tm_op_to_cb8(const void* x_ncdhw, void* y_cb8, int N, int C, int Z, int H, int W, void* stream);
 int tm_op_from_cb8(const void* x_cb8, void* y_ncdhw, int N, int C, int Z, int H, int W, void* stream);
 
-/* Conv3d k=3x3x3 pad 1 (Z must be 2) or k=1x1x1 on the MFMA implicit-GEMM kernel
- * (replaces nn.Conv3d as used in ResBlock, model/MBAblocks.py:146-148,182-186,220-224).
- *   w [Cout][Cin][k][k][k] HOST fp32, bias [Cout] HOST fp32; x, y CB8 DEVICE. */
+/* Conv3d on the MFMA implicit-GEMM kernels (replaces nn.Conv3d as used in ResBlock,
+ * model/MBAblocks.py:146-148,182-186,220-224, the RNA pyramid convs model/unet_ours.py:290-295
+ * and down_z model/MBAblocks.py:472-474).  ksize 1: 1x1x1.  ksize 3 with zmode
+ *   0: 3x3x3 pad (1,1,1), Z == 2      1: 1x3x3 pad (0,1,1)      2: 3x3x3 pad (0,1,1) (Zout = Z-2).
+ * up2: nearest x2 on (H, W) applied to the output.  w [Cout][Cin][kz][3][3] HOST fp32,
+ * bias [Cout] HOST fp32; x, y CB8 DEVICE. */
 int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
-                    int N, int Cin, int Cout, int Z, int S, int ksize, int tile_variant,
-                    void* stream);
+                    int N, int Cin, int Cout, int Z, int S, int ksize, int zmode, int up2,
+                    int tile_variant, void* stream);
 
 /* Generic direct Conv3d (stem / head / RNA path), NCDHW in, NCDHW out. */
 int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N,

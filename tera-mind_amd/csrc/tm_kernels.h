@@ -38,6 +38,7 @@ void conv_pack_host(const float* w /*[Cout][Cin][taps]*/, int Cout, const int* s
 void vec_pack_host(const float* v, const int* seg_c, int nseg, float* out);  // per-cin vector -> virtual order
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_UP2 = 2 };
+enum { ZM_PAD1 = 0, ZM_INPLANE = 1, ZM_VALID = 2 };   // z structure of a k x 3 x 3 conv (see conv3d_mfma)
 struct ConvLaunch {
   TV x;                  // activated input, Cb == w.Cbi
   ConvW w;
@@ -46,6 +47,7 @@ struct ConvLaunch {
   const TV* gate = nullptr;  // optional gate: y = res + gate * (conv + bias)
   int flags = 0;
   int tile_variant = 0;  // 0 auto, 1 = 128-voxel blocks, 2 = 256-voxel blocks
+  int zmode = ZM_PAD1;   // ignored for taps == 1
 };
 hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s);
 
@@ -97,6 +99,11 @@ struct DirectLaunch {
 };
 hipError_t launch_conv_direct(const DirectLaunch& L, hipStream_t s);
 
+// stem: x NCHW '(s z) h w' [N][Cin*Z][S][S] -> y CB8; w [9][Cin][y.Cb*8]
+hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s);
+// head: x CB8 (Cb blocks) -> y NCHW [N][Cout*Z][S][S]; w [9][x.Cb*8][8]
+hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s);
+
 // ---- layout converters ----------------------------------------------------------------
 hipError_t launch_to_cb8(const float* x, TV y, hipStream_t s);        // NCDHW -> CB8 (zero pads)
 hipError_t launch_from_cb8(TV x, float* y, hipStream_t s);            // CB8 -> NCDHW
@@ -113,7 +120,7 @@ hipError_t launch_emb_all(const float* te, int b, int E, const float* wall, cons
 struct GeneW {       // all device pointers; matrices stored TRANSPOSED [in][out]
   const float *wq_t, *bq, *wv_t, *bv, *qnorm, *wp_t, *bp, *norm2, *w1_t, *b1, *w2_t, *b2;
 };
-// rna dense [B][gn][gn][zs*500] -> tokens out [B][G][D] (D = zs*gn*gn, order z h w);
+// rna dense [B][gn][gn][zs*500] -> tokens out as CB8 [B][ceil(G/8)][zs][gn][gn][8] (pad slots untouched);
 // zmask_lo/hi: slices outside [lo,hi) are treated as zero (attention-map variants).
 hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, const GeneW& w,
                             float* out_tok /*nullable*/, float* attn_map /*nullable [B][G][G]*/,

@@ -5,7 +5,7 @@
 // for coalesced HBM traffic, (c) a channel concat is a list of block ranges.
 //
 // Kernels (reference op each one replaces is cited at its definition):
-//   conv27_mfma / conv1_mfma   implicit-GEMM Conv3d on v_mfma_f32_32x32x2_f32 (exact fp32)
+//   conv3d_mfma / conv1_mfma   implicit-GEMM Conv3d on v_mfma_f32_32x32x2_f32 (exact fp32)
 //   prep_kernel                concat + collage/up/down gather + RMSNorm(C) + modulate + SiLU
 //   conv_direct_kernel         small convs (stem, head, RNA path) on VALU
 //   gene_attn_kernel           gene-gene attention block, one workgroup per patch
@@ -113,24 +113,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
   }
 }
 
-template <int WM, int TW>
-struct C27Geo {
-  static constexpr int MV = 4 * WM * 32;                 // voxels per workgroup
-  static constexpr int TR = (TW == 8) ? 8 : (MV / TW);   // tile rows
-  static constexpr int NPB = MV / (TR * TW);             // patches per workgroup
+// NZI selects the z structure of the k x 3 x 3 kernel:
+//   NZI = 2  3x3x3, pad (1,1,1), Z == 2: the z-skip form above (18 of 27 taps per output plane)
+//   NZI = 1  1x3x3, pad (0,1,1): in-plane conv, any Z   (RNA pyramid, model/unet_ours.py:290-295)
+//   NZI = 3  3x3x3, pad (0,1,1): valid in z, Zin = Zout + 2 (down_z, model/MBAblocks.py:472-474)
+template <int NZI, int WM, int TW>
+struct C3Geo {
+  static constexpr int MV = 4 * WM * 32;                         // voxels per workgroup
+  static constexpr int TR = (MV / TW < TW) ? (MV / TW) : TW;     // tile rows (<= plane size S == TW or 2*TW)
+  static constexpr int NPB = MV / (TR * TW);                     // patches per workgroup
   static constexpr int HR = TR + 2, HC = TW + 2;
-  static constexpr int XV = NPB * 2 * HR * HC;           // halo voxels (2 input planes)
-  static constexpr int XPIECES = XV * 2;                 // 16-byte pieces
+  static constexpr int XV = NPB * NZI * HR * HC;                 // halo voxels
+  static constexpr int XPIECES = XV * 2;                         // 16-byte pieces
   static constexpr int PX = (XPIECES + 255) / 256;
-  static constexpr int WFLOATS = 18 * 64 * 8;
-  static constexpr int PW = WFLOATS / 4 / 256;           // = 9
-  static constexpr int LDS_FLOATS = WFLOATS + XV * 8;
+  static constexpr int NTAP = 9 * NZI;                           // taps staged per channel block
+  static constexpr int WFLOATS = NTAP * 512;
+  static constexpr int WPIECES = WFLOATS / 4;
+  static constexpr int PW = (WPIECES + 255) / 256;
+  static constexpr int TAPS_TOTAL = (NZI == 1) ? 9 : 27;         // taps per channel block in the packed weights
+  static constexpr int LDS_BYTES = (WFLOATS + XV * 8) * 4;
 };
 
-template <int WM, int TW>
-__global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
-  using G = C27Geo<WM, TW>;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+template <int NZI, int WM, int TW>
+__global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
+  using G = C3Geo<NZI, WM, TW>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lw = lds;
   float* lx = lds + G::WFLOATS;
 
@@ -144,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
   const int bid = blockIdx.x;
   const int nt = bid % a.ntile;
   int mt_ = bid / a.ntile;
-  const int pg = mt_ / (2 * tiles);
-  mt_ -= pg * 2 * tiles;
+  const int pg = mt_ / (a.Z * tiles);                            // a.Z = OUTPUT planes
+  mt_ -= pg * a.Z * tiles;
   const int zo = mt_ / tiles;
   mt_ -= zo * tiles;
   const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
@@ -161,18 +168,20 @@ __global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
       int v = i >> 1;
       const int hc = v % G::HC; v /= G::HC;
       const int hr = v % G::HR; v /= G::HR;
-      const int zi = v & 1;
-      const int ps = v >> 1;
+      const int zi = v % NZI;
+      const int ps = v / NZI;
+      const int zs = (NZI == 2) ? zi : zo + zi;                  // source plane
       const int n = pg * G::NPB + ps;
       const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
       if (n < a.N && y >= 0 && y < S && x >= 0 && x < S)
-        off = (long)n * a.x_nstride + ((long)(zi * S + y) * S + x) * 8 + half * 4;
+        off = (long)n * a.x_nstride + ((long)(zs * S + y) * S + x) * 8 + half * 4;
     }
     xoff[k] = off;
   }
-  // weights: taps [(1-zo)*9, (1-zo)*9+18) of this (n-tile, cblk) are contiguous
-  const float* wsrc = a.w + ((long)nt * a.Cbi * 27 + (1 - zo) * 9) * 512 + tid * 4;
-  const long w_cb_stride = 27 * 512;
+  // weights: the staged taps of this (n-tile, cblk) are contiguous; NZI == 2 starts at kz = 1 - zo
+  const int tap0 = (NZI == 2) ? (1 - zo) * 9 : 0;
+  const float* wsrc = a.w + ((long)nt * a.Cbi * G::TAPS_TOTAL + tap0) * 512 + tid * 4;
+  const long w_cb_stride = G::TAPS_TOTAL * 512;
 
   // ---- per-lane fragment addresses ----
   int xb[WM];
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
     const int ps = v / (G::TR * TW);
     const int rem = v - ps * (G::TR * TW);
     const int r = rem / TW, c = rem - r * TW;
-    xb[mt] = ((ps * 2 * G::HR + r) * G::HC + c) * 8 + 4 * h;
+    xb[mt] = ((ps * NZI * G::HR + r) * G::HC + c) * 8 + 4 * h;
     const int n = pg * G::NPB + ps;
     on[mt] = n;
     const int y = tr * G::TR + r, x = tc * TW + c;
@@ -210,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
     for (int k = 0; k < G::PX; ++k) xr[k] = (xoff[k] >= 0) ? *(const f32x4*)(xp + xoff[k]) : zero4;
     const float* wp = wsrc + (long)cb * w_cb_stride;
 #pragma unroll
-    for (int k = 0; k < G::PW; ++k) wr[k] = *(const f32x4*)(wp + k * 1024);
+    for (int k = 0; k < G::PW; ++k)
+      if (G::WPIECES % 256 == 0 || tid + k * 256 < G::WPIECES) wr[k] = *(const f32x4*)(wp + k * 1024);
   };
 
   load_stage(0);
@@ -220,12 +230,13 @@ __global__ __launch_bounds__(256, 2) void conv27_mfma(ConvArgs a) {
     for (int k = 0; k < G::PX; ++k)
       if (tid + k * 256 < G::XPIECES) *(f32x4*)(lx + (tid + k * 256) * 4) = xr[k];
 #pragma unroll
-    for (int k = 0; k < G::PW; ++k) *(f32x4*)(lw + (tid + k * 256) * 4) = wr[k];
+    for (int k = 0; k < G::PW; ++k)
+      if (G::WPIECES % 256 == 0 || tid + k * 256 < G::WPIECES) *(f32x4*)(lw + (tid + k * 256) * 4) = wr[k];
     __syncthreads();
     if (cb + 1 < a.Cbi) load_stage(cb + 1);
 
 #pragma unroll
-    for (int zi = 0; zi < 2; ++zi) {
+    for (int zi = 0; zi < NZI; ++zi) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -420,25 +431,54 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
     }
     return hipGetLastError();
   }
-  if (L.w.taps != 27 || a.Z != 2) return hipErrorInvalidValue;
+  // ---- k x 3 x 3 kernels ----
   const int S = a.S;
-  if (S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
+  int nzi;
+  if (L.zmode == ZM_PAD1) {            // 3x3x3 pad 1, Z == 2
+    if (L.w.taps != 27 || L.x.Z != 2 || L.y.Z != 2) return hipErrorInvalidValue;
+    nzi = 2;
+  } else if (L.zmode == ZM_INPLANE) {  // 1x3x3
+    if (L.w.taps != 9 || L.y.Z != L.x.Z) return hipErrorInvalidValue;
+    nzi = 1;
+  } else if (L.zmode == ZM_VALID) {    // 3x3x3 valid in z
+    if (L.w.taps != 27 || L.y.Z != L.x.Z - 2) return hipErrorInvalidValue;
+    nzi = 3;
+  } else return hipErrorInvalidValue;
+  a.Z = L.y.Z;
+  if (S != 4 && S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
   if ((L.flags & EPI_UP2) ? (L.y.H != 2 * S) : (L.y.H != S)) return hipErrorInvalidValue;
-  int variant = L.tile_variant ? L.tile_variant : ((vox / 256) * a.ntile >= 512 ? 2 : 1);
-#define TM_LAUNCH27(WM, TW)                                                                     \
+  const long ovox = (long)a.N * a.Z * a.S * a.S;
+  int variant = L.tile_variant ? L.tile_variant : ((ovox / 256) * a.ntile >= 512 ? 2 : 1);
+#define TM_LAUNCH3(NZI, WM, TW)                                                                  \
   do {                                                                                          \
-    using G = C27Geo<WM, TW>;                                                                   \
+    using G = C3Geo<NZI, WM, TW>;                                                               \
+    static bool attr_done = false;                                                              \
+    if (!attr_done) {                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_mfma<NZI, WM, TW>,                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_done = true;                                                                         \
+    }                                                                                           \
     const long tiles = (long)(S / TW) * (S / G::TR);                                            \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
-    const long grid = pgs * 2 * tiles * a.ntile;                                                \
-    hipLaunchKernelGGL((conv27_mfma<WM, TW>), dim3((unsigned)grid), dim3(256), 0, s, a);        \
+    const long grid = pgs * a.Z * tiles * a.ntile;                                              \
+    hipLaunchKernelGGL((conv3d_mfma<NZI, WM, TW>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a); \
   } while (0)
-  if (variant == 2) {
-    if (S >= 32) TM_LAUNCH27(2, 32); else if (S == 16) TM_LAUNCH27(2, 16); else TM_LAUNCH27(2, 8);
+  if (nzi == 2) {
+    if (S < 8) return hipErrorInvalidValue;
+    if (variant == 2) {
+      if (S >= 32) TM_LAUNCH3(2, 2, 32); else if (S == 16) TM_LAUNCH3(2, 2, 16); else TM_LAUNCH3(2, 2, 8);
+    } else {
+      if (S >= 32) TM_LAUNCH3(2, 1, 32); else if (S == 16) TM_LAUNCH3(2, 1, 16); else TM_LAUNCH3(2, 1, 8);
+    }
+  } else if (nzi == 1) {
+    if (S < 8) return hipErrorInvalidValue;
+    if (S >= 32) TM_LAUNCH3(1, 2, 32); else if (S == 16) TM_LAUNCH3(1, 2, 16); else TM_LAUNCH3(1, 2, 8);
   } else {
-    if (S >= 32) TM_LAUNCH27(1, 32); else if (S == 16) TM_LAUNCH27(1, 16); else TM_LAUNCH27(1, 8);
+    if (S != 4) return hipErrorInvalidValue;
+    TM_LAUNCH3(3, 1, 4);
   }
-#undef TM_LAUNCH27
+#undef TM_LAUNCH3
   return hipGetLastError();
 }
 
@@ -684,6 +724,107 @@ hipError_t launch_conv_direct(const DirectLaunch& L, hipStream_t s) {
 }
 
 // ==========================================================================================
+// Stem Conv3d(n_stain -> 64k, (1,3,3)) straight from the NCHW '(s z) h w' state into CB8
+// (model/unet_ours.py:110-114,377) and head Conv3d(64 -> n_stain, (1,3,3)) from CB8 straight
+// into the NCHW eps tensor (:274-275,424).  lane = voxel; weights are wave-uniform (scalar loads).
+// ==========================================================================================
+struct StemArgs {
+  const float* x; float* y; const float* w; const float* bias;   // w: [tap 9][ci][Cop]
+  int N, Cin, Cout, Cop, Z, S;
+  long y_nstride;
+};
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+  const int S = a.S;
+  const long vpn = (long)a.Z * S * S;
+  const long vidx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (vidx >= vpn * a.N) return;
+  const int n = (int)(vidx / vpn);
+  int rem = (int)(vidx - (long)n * vpn);
+  const int z = rem / (S * S); rem -= z * S * S;
+  const int y = rem / S, x = rem - y * S;
+  const int cob0 = blockIdx.y * 4;                 // 4 cout blocks (32 couts) per thread
+  float acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc[j] = a.bias[cob0 * 8 + j];
+  for (int ci = 0; ci < a.Cin; ++ci) {
+    const float* xp = a.x + (((long)n * a.Cin + ci) * a.Z + z) * S * S;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yi = y + ky - 1, xi = x + kx - 1;
+        const float xv = (yi >= 0 && yi < S && xi >= 0 && xi < S) ? xp[yi * S + xi] : 0.f;
+        const float* wp = a.w + ((long)(ky * 3 + kx) * a.Cin + ci) * a.Cop + cob0 * 8;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = fmaf(wp[j], xv, acc[j]);
+      }
+    }
+  }
+  float* yp = a.y + (long)n * a.y_nstride + ((long)(z * S + y) * S + x) * 8;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float* p = yp + (long)(cob0 + b) * vpn * 8;
+    *(f32x4*)p = f32x4{acc[b * 8 + 0], acc[b * 8 + 1], acc[b * 8 + 2], acc[b * 8 + 3]};
+    *(f32x4*)(p + 4) = f32x4{acc[b * 8 + 4], acc[b * 8 + 5], acc[b * 8 + 6], acc[b * 8 + 7]};
+  }
+}
+hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s) {
+  if (y.C % 32) return hipErrorInvalidValue;
+  StemArgs a{x, y.p, w, bias, y.N, Cin, y.C, y.Cb * 8, y.Z, y.H, y.nstride};
+  const long vox = (long)y.N * y.Z * y.H * y.W;
+  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((vox + 255) / 256), (unsigned)(y.C / 32)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+struct HeadArgs {
+  const float* x; long x_nstride; int Cb;
+  float* y; const float* w; const float* bias;                    // w: [tap 9][ci][8]
+  int N, Cout, Z, S;
+};
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+  const int S = a.S;
+  const long vpn = (long)a.Z * S * S;
+  const long vidx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (vidx >= vpn * a.N) return;
+  const int n = (int)(vidx / vpn);
+  int rem = (int)(vidx - (long)n * vpn);
+  const int z = rem / (S * S); rem -= z * S * S;
+  const int y = rem / S, x = rem - y * S;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const float* xb = a.x + (long)n * a.x_nstride;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yi = y + ky - 1, xi = x + kx - 1;
+      if (yi < 0 || yi >= S || xi < 0 || xi >= S) continue;
+      const float* xp = xb + ((long)(z * S + yi) * S + xi) * 8;
+      const float* wt = a.w + (long)(ky * 3 + kx) * a.Cb * 64;
+      for (int cb = 0; cb < a.Cb; ++cb) {
+        const f32x4 a0 = *(const f32x4*)(xp + (long)cb * vpn * 8), a1 = *(const f32x4*)(xp + (long)cb * vpn * 8 + 4);
+        const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const float* wp = wt + cb * 64;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(wp[c * 8 + j], xv[c], acc[j]);
+      }
+    }
+  }
+  for (int j = 0; j < a.Cout; ++j)
+    a.y[(((long)n * a.Cout + j) * a.Z + z) * S * S + (long)y * S + x] = acc[j] + a.bias[j];
+}
+hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s) {
+  if (Cout > 8) return hipErrorInvalidValue;
+  HeadArgs a{x.p, x.nstride, x.Cb, y, w, bias, x.N, Cout, x.Z, x.H};
+  const long vox = (long)x.N * x.Z * x.H * x.W;
+  hipLaunchKernelGGL(head_kernel, dim3((unsigned)((vox + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ==========================================================================================
 // layout converters
 // ==========================================================================================
 __global__ void to_cb8_kernel(const float* x, float* y, int N, int C, int Cb, long vpn, long y_nstride) {
@@ -791,7 +932,8 @@ hipError_t launch_emb_all(const float* te, int b, int E, const float* wall, cons
 // ==========================================================================================
 // Gene-gene attention block (AttnBlock gene_trans=False: model/MBAblocks.py:492-501 and
 // Attention.forward :551-601 with k = q, q_norm on both, scale 1/64, no residuals), one
-// workgroup per patch, tokens = G genes x D = 64 features (z h w).  The softmax row lives
+// workgroup per patch, tokens = G genes x D = 64 features (z h w); the result is written as the
+// CB8 tensor [B][ceil(G/8)][zs][gn][gn][8] that down_z consumes.  The softmax row lives
 // across the 64 lanes of a wave (4 keys per lane) and is reduced with wave shuffles.
 // P.V is computed as (P.tok).Wv^T + bv (rows of P sum to 1), so V is never materialised.
 // ==========================================================================================
@@ -804,18 +946,27 @@ struct GeneArgs {
 #define GENE_D 64
 #define GENE_QP 65      // padded row of the normalised-q image: conflict-free key reads
 
-__global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
+#define GENE_WAVES 4
+#define GENE_SPLIT 2      // workgroups per patch: rows of passes B/C are interleaved over them
+// token (n, gene g, feature d = (z h w)) inside the CB8 tensor [B][ceil(G/8)][zs][gn][gn][8]
+__device__ __forceinline__ long gene_tok_idx(int n, int g, int d, int Gb) {
+  return (((long)n * Gb + (g >> 3)) * GENE_D + d) * 8 + (g & 7);
+}
+
+__global__ __launch_bounds__(64 * GENE_WAVES) void gene_attn_kernel(GeneArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int G = a.G;
   float* tok = sm;                       // [G][64]
   float* qn = tok + G * GENE_D;          // [G][65]
-  float* prow = qn + G * GENE_QP;        // [4][Gp]
+  float* prow = qn + G * GENE_QP;        // [GENE_WAVES][Gp]
   const int Gp = (G + 63) / 64 * 64;
+  const int Gb = (G + 7) / 8;
+  constexpr int NT = 64 * GENE_WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = blockIdx.x;
   const int gg = a.gn * a.gn;
   const long rbase = (long)n * gg * a.zs * 500;
-  for (int i = tid; i < G * GENE_D; i += 256) {
+  for (int i = tid; i < G * GENE_D; i += NT) {
     const int d = i / G, g = i - d * G;
     const int z = d / gg, hw = d - z * gg;
     float v = 0.f;
@@ -829,7 +980,7 @@ __global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
 #pragma unroll
     for (int k = 0; k < GENE_D; ++k) wq[k] = a.w.wq_t[k * GENE_D + lane];
     const float bq = a.w.bq[lane], qw = a.w.qnorm[lane];
-    for (int g = wv; g < G; g += 4) {
+    for (int g = wv; g < G; g += GENE_WAVES) {
       float acc = bq;
 #pragma unroll
       for (int k = 0; k < GENE_D; ++k) acc = fmaf(tok[g * GENE_D + k], wq[k], acc);
@@ -847,7 +998,7 @@ __global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
       for (int k = 0; k < GENE_D; ++k) { wvv[k] = a.w.wv_t[k * GENE_D + lane]; wpp[k] = a.w.wp_t[k * GENE_D + lane]; }
     }
     float* pr = prow + wv * Gp;
-    for (int g = wv; g < G; g += 4) {
+    for (int g = wv + GENE_WAVES * blockIdx.y; g < G; g += GENE_WAVES * GENE_SPLIT) {
       float lg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
       for (int d = 0; d < GENE_D; ++d) {
@@ -893,7 +1044,7 @@ __global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
       for (int k = 0; k < GENE_D; ++k) op = fmaf(__shfl(ov, k, 64), wpp[k], op);
       const float ss = wave_sum(op * op);
       const float rstd = 1.0f / sqrtf(ss * (1.0f / GENE_D) + TM_EPS);
-      a.scratch[((long)n * G + g) * GENE_D + lane] = a.w.norm2[lane] * (op * rstd);
+      a.scratch[gene_tok_idx(n, g, lane, Gb)] = a.w.norm2[lane] * (op * rstd);
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -902,10 +1053,10 @@ __global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
   // ---- pass C: MLP 64 -> 256 (tanh-GELU) -> 64, weights staged in the freed LDS ----
   float* w1 = sm;                  // [64][256]
   float* w2 = sm + 64 * 256;       // [256][64]
-  for (int i = tid; i < 64 * 256; i += 256) { w1[i] = a.w.w1_t[i]; w2[i] = a.w.w2_t[i]; }
+  for (int i = tid; i < 64 * 256; i += NT) { w1[i] = a.w.w1_t[i]; w2[i] = a.w.w2_t[i]; }
   __syncthreads();
-  for (int g = wv; g < G; g += 4) {
-    const float hv = a.scratch[((long)n * G + g) * GENE_D + lane];
+  for (int g = wv + GENE_WAVES * blockIdx.y; g < G; g += GENE_WAVES * GENE_SPLIT) {
+    const float hv = a.scratch[gene_tok_idx(n, g, lane, Gb)];
     float y1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) y1[j] = a.w.b1[lane + 64 * j];
@@ -922,13 +1073,13 @@ __global__ __launch_bounds__(256) void gene_attn_kernel(GeneArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int k = 0; k < 64; ++k) y2 = fmaf(__shfl(y1[j], k, 64), w2[(k + 64 * j) * 64 + lane], y2);
-    a.out_tok[((long)n * G + g) * GENE_D + lane] = y2;
+    a.out_tok[gene_tok_idx(n, g, lane, Gb)] = y2;
   }
 }
 
 static size_t gene_lds_bytes(int G) {
   const int Gp = (G + 63) / 64 * 64;
-  size_t a = ((size_t)G * GENE_D + (size_t)G * GENE_QP + 4 * Gp) * sizeof(float);
+  size_t a = ((size_t)G * GENE_D + (size_t)G * GENE_QP + GENE_WAVES * Gp) * sizeof(float);
   size_t b = (size_t)2 * 64 * 256 * sizeof(float);
   return a > b ? a : b;
 }
@@ -947,7 +1098,7 @@ hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, cons
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gene_attn_kernel, dim3(B), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(gene_attn_kernel, dim3(B, GENE_SPLIT), dim3(64 * GENE_WAVES), lds, s, a);
   return hipGetLastError();
 }
 

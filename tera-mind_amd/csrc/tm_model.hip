@@ -88,7 +88,8 @@ struct tm_model {
   const float *te_w1 = nullptr, *te_b1 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
   const float *emb_w = nullptr, *emb_b = nullptr;
   GeneW gene;
-  DirectW downz, pyr[3], stem, head;
+  ConvW downz, pyr[3];
+  DirectW stem, head;
   const float* out_norm = nullptr;
   // measurement hooks (tm_profile_*)
   bool prof_on = false;
@@ -423,11 +424,12 @@ extern "C" int tm_model_finalize(tm_model* m) {
     pack_raw(pk, fx, &m->gene.b1, P(m, g + ".mlp.fc1.bias"));
     pack_transposed(pk, fx, &m->gene.w2_t, P(m, g + ".mlp.fc2.weight"), d, 4 * d);
     pack_raw(pk, fx, &m->gene.b2, P(m, g + ".mlp.fc2.bias"));
-    pack_direct(m, pk, fx, m->downz, g + ".down_z", c.rna_num, c.rna_num, (int)m->host[g + ".down_z.weight"].shape[2], 3, 3);
+    pack_conv(m, pk, fx, m->downz, g + ".down_z.weight", g + ".down_z.bias", c.rna_num, {c.rna_num}, 27);
   }
   if (!c.vis_only) {
     for (int rid = 1; rid < 4; ++rid)
-      pack_direct(m, pk, fx, m->pyr[rid - 1], "rna_blocks." + std::to_string(rid) + ".1", m->rw[rid], m->rw[rid - 1], 1, 3, 3);
+      pack_conv(m, pk, fx, m->pyr[rid - 1], "rna_blocks." + std::to_string(rid) + ".1.weight",
+                "rna_blocks." + std::to_string(rid) + ".1.bias", m->rw[rid], {m->rw[rid - 1]}, 9);
     pack_direct(m, pk, fx, m->stem, "input_blocks.0.0", c.net_ch, c.n_stain, 1, 3, 3);
     pack_direct(m, pk, fx, m->head, "out.2", c.n_stain, c.net_ch, 1, 3, 3);
     pack_raw(pk, fx, &m->out_norm, P(m, "out.0.weight"));
@@ -562,12 +564,12 @@ static void dump_tv(Ctx& cx, const std::string& name, const TV& t) {
 }
 
 static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags,
-                     int cin_real = 0) {
+                     int cin_real = 0, int zmode = ZM_PAD1) {
   if (cx.dry) return;
   ConvLaunch L;
-  L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
+  L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags; L.zmode = zmode;
   tm_model* m = cx.m;
-  const bool prof = m->prof_on && w.taps == 27;
+  const bool prof = m->prof_on && w.taps == 27 && zmode == ZM_PAD1;
   if (prof) {
     if (m->prof_used == m->prof_ev.size()) {
       hipEvent_t a, b;
@@ -640,11 +642,13 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
 }
 
 // AttnBlock._forward with cond (model/MBAblocks.py:484-489); x updated in place
-static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_image) {
+static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_image, const TV* cond_act = nullptr) {
   const size_t mark = cx.top;
   const int N = x.N, Z = x.Z, S = x.H, C = w.C, cb = C / 8;
-  TV cact = cx.tensor(N, (w.G + 7) / 8 * 8, Z, S);
-  if (!cx.dry) {
+  // SiLU(cond) (adaLN_modulation[0], MBAblocks.py:464): reuse the activated RNA level when the
+  // cond is not re-tiled (encoder / middle), gather + activate for the collage decoder
+  TV cact = cond_act ? *cond_act : cx.tensor(N, (w.G + 7) / 8 * 8, Z, S);
+  if (!cx.dry && !cond_act) {
     PrepLaunch P;
     P.nsrc = 1;
     P.src[0].p = cond.t.p; P.src[0].nstride = cond.t.nstride; P.src[0].Cb = cond.t.Cb;
@@ -707,24 +711,34 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
     cx.check(launch_emb_all(te, b, c.embed_ch, m->emb_w, m->emb_b, m->emb_tot, ss, cx.s));
   }
   // ---- RNA pyramid (get_rna, model/unet_ours.py:298-323) ----
-  float* tok = cx.alloc_f((size_t)Ne * c.rna_num * m->D);
-  if (!cx.dry) cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok, nullptr, 0, c.rna_slc, cx.s));
-  TV rl[4];
+  TV tok = cx.tensor(Ne, c.rna_num, c.rna_slc, m->gn);           // gene-attention output, CB8 [Ne][Gb][zs][gn][gn][8]
+  if (!cx.dry) {
+    cx.check(hipMemsetAsync(tok.p, 0, (size_t)Ne * tok.nstride * sizeof(float), cx.s));      // pad gene slots
+    cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok.p, nullptr, 0, c.rna_slc, cx.s));
+  }
+  TV rl[4], rs[3];                                               // rna levels and SiLU(level) (pyramid + adaLN input)
   int S = m->gn * 2;
   rl[0] = cx.tensor(Ne, m->rw[0], Z, S);
-  if (!cx.dry) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));
-  run_direct(cx, m->downz, tok, acc_ncdhw(c.rna_num, c.rna_slc, m->gn, m->gn), rl[0].p, acc_cb8(rl[0]), Ne, c.rna_slc,
-             Z, m->gn, 0, 0, 1);
+  run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
   for (int i = 1; i < 4; ++i) {
+    rs[i - 1] = cx.tensor(Ne, m->rw[i - 1], Z, S);
+    if (!cx.dry) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = rl[i - 1].p; P.src[0].nstride = rl[i - 1].nstride; P.src[0].Cb = rl[i - 1].Cb;
+      P.N = Ne; P.Z = Z; P.S = S; P.act = 1;
+      P.out = rs[i - 1].p; P.out_nstride = rs[i - 1].nstride;
+      cx.check(launch_prep(P, cx.s));
+    }
     rl[i] = cx.tensor(Ne, m->rw[i], Z, S * 2);
-    run_direct(cx, m->pyr[i - 1], rl[i - 1].p, acc_cb8(rl[i - 1]), rl[i].p, acc_cb8(rl[i]), Ne, Z, Z, S, 0, 1, 1);
+    run_conv(cx, rs[i - 1], m->pyr[i - 1], rl[i], nullptr, nullptr, EPI_UP2, 0, ZM_INPLANE);   // SiLU -> conv -> Upsample
     S *= 2;
   }
   for (int i = 0; i < 4; ++i) { TV v = rl[i]; v.C = m->rw[i]; dump_tv(cx, "rna." + std::to_string(i), v); }
   // ---- stem ----
   std::vector<std::vector<TV>> skips(L);
   TV h = cx.tensor(Ne, c.net_ch, Z, ps);
-  run_direct(cx, m->stem, x, acc_ncdhw(c.n_stain, Z, ps, ps), h.p, acc_cb8(h), Ne, Z, Z, ps, 0, 0, 0);
+  if (!cx.dry) cx.check(launch_stem(x, h, m->stem.w, m->stem.bias, c.n_stain, cx.s));
   skips[0].push_back(h);
   dump_tv(cx, "stem", h);
   // ---- encoder ----
@@ -736,7 +750,7 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
     if (e.cat) src.push_back({cond, false});
     for (const Op& op : e.ops) {
       if (op.kind == 0) h = res_block(cx, m->res[op.idx], src, Ne, ne_img, So, op.mode, nullptr);
-      else attn_block(cx, m->attn[op.idx], h, {cond, false}, ne_img);
+      else attn_block(cx, m->attn[op.idx], h, {cond, false}, ne_img, (L - 1 - e.lvl) < 3 ? &rs[L - 1 - e.lvl] : nullptr);
     }
     skips[e.lvl].push_back(h);
     const Op& last = e.ops.back();
@@ -747,7 +761,7 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
     std::vector<Src> src = {{h, false}, {rl[0], false}};
     const int So = ps >> (L - 1);
     h = res_block(cx, m->res[m->mid[0].idx], src, Ne, ne_img, So, RS_SAME, nullptr);
-    attn_block(cx, m->attn[m->mid[1].idx], h, {rl[0], false}, ne_img);
+    attn_block(cx, m->attn[m->mid[1].idx], h, {rl[0], false}, ne_img, &rs[0]);
     std::vector<Src> src2 = {{h, false}};
     h = res_block(cx, m->res[m->mid[2].idx], src2, Ne, ne_img, So, RS_SAME, nullptr);
     dump_tv(cx, "middle_block", h);
@@ -783,7 +797,7 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
       P.out = A.p; P.out_nstride = A.nstride;
       cx.check(launch_prep(P, cx.s));
     }
-    run_direct(cx, m->head, A.p, acc_cb8(A), outp, acc_ncdhw(c.n_stain, Z, ps, ps), N, Z, Z, ps, 0, 0, 0);
+    if (!cx.dry) cx.check(launch_head(A, outp, m->head.w, m->head.bias, c.n_stain, cx.s));
     cx.top = mark;
   };
   decode(true, pred);
@@ -884,9 +898,12 @@ extern "C" int tm_op_from_cb8(const void* x, void* y, int N, int C, int Z, int H
   return TM_OK;
 }
 extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
-                               int Cout, int Z, int S, int ksize, int tile_variant, void* stream) {
+                               int Cout, int Z, int S, int ksize, int zmode, int up2, int tile_variant, void* stream) {
   if (ksize != 1 && ksize != 3) return fail(TM_ERR_ARG, "ksize must be 1 or 3");
-  const int taps = ksize == 3 ? 27 : 1;
+  if (zmode != ZM_PAD1 && zmode != ZM_INPLANE && zmode != ZM_VALID) return fail(TM_ERR_ARG, "bad zmode");
+  const int taps = ksize == 1 ? 1 : (zmode == ZM_INPLANE ? 9 : 27);
+  const int Zout = (ksize == 3 && zmode == ZM_VALID) ? Z - 2 : Z;
+  const int So = up2 ? 2 * S : S;
   ConvW cw;
   cw.Cout = Cout; cw.Cbi = (Cin + 7) / 8; cw.taps = taps; cw.ntile = (Cout + 63) / 64;
   std::vector<float> pk(conv_pack_floats(Cout, cw.Cbi, taps)), bp((size_t)cw.ntile * 64, 0.f);
@@ -901,8 +918,10 @@ extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void
   ConvLaunch L;
   L.x = view_cb8(const_cast<void*>(x_cb8), N, Cin, Z, S, S);
   L.w = cw;
-  L.y = view_cb8(y_cb8, N, Cout, Z, S, S);
+  L.y = view_cb8(y_cb8, N, Cout, Zout, So, So);
   L.tile_variant = tile_variant;
+  L.zmode = zmode;
+  L.flags = up2 ? EPI_UP2 : 0;
   hipError_t e = launch_conv_mfma(L, (hipStream_t)stream);
   hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(dw); (void)hipFree(db);

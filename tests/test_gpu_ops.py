@@ -82,3 +82,31 @@ def test_conv_direct(N, Cin, Cout, Zin, S, k, pad, silu, up2):
         ref = ref.repeat_interleave(2, -2).repeat_interleave(2, -1)
     got = util.conv_direct(x.to(DEV), w, b, pad, silu, up2)
     assert torch.allclose(got.cpu(), ref, atol=2e-5, rtol=1e-5), util.report("direct", got, ref)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,S", [(3, 229, 128, 8), (2, 128, 64, 16), (2, 64, 32, 32), (5, 13, 40, 8)])
+@pytest.mark.parametrize("up2", [False, True])
+def test_conv_inplane_mfma_exact_integers(N, Cin, Cout, S, up2):
+    """1x3x3 in-plane conv (RNA pyramid) + fused nearest-x2 store."""
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 21)
+    w = util.rand_int((Cout, Cin, 1, 3, 3), -2, 2, 22)
+    b = util.rand_int((Cout,), -4, 4, 23)
+    ref = F.conv3d(x, w, b, padding=(0, 1, 1))
+    if up2:
+        ref = ref.repeat_interleave(2, -2).repeat_interleave(2, -1)
+    got, _ = util.conv_mfma(x.to(DEV), w, b, 3, zmode=1, up2=up2)
+    assert torch.equal(got.cpu(), ref), util.report("conv 1x3x3", got, ref)
+
+
+@pytest.mark.parametrize("N,Cin,Cout", [(3, 229, 229), (9, 16, 64), (17, 24, 72)])
+def test_conv_validz_mfma_exact_integers(N, Cin, Cout):
+    """3x3x3 valid-in-z conv on 4x4x4 gene volumes (down_z) + fused nearest-x2 store."""
+    x = util.rand_int((N, Cin, 4, 4, 4), -3, 3, 31)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 32)
+    b = util.rand_int((Cout,), -4, 4, 33)
+    ref = F.conv3d(x, w, b, padding=(0, 1, 1)).repeat_interleave(2, -2).repeat_interleave(2, -1)
+    got, raw = util.conv_mfma(x.to(DEV), w, b, 3, zmode=2, up2=True)
+    assert got.shape == (N, Cout, 2, 8, 8)
+    assert torch.equal(got.cpu(), ref), util.report("down_z", got, ref)
+    if Cout % 8:
+        assert float(raw[:, -1, ..., Cout % 8:].abs().max()) == 0.0

@@ -44,15 +44,18 @@ def from_cb8(y, Cc):
     return x
 
 
-def conv_mfma(x, w, b, ksize, variant=0):
+def conv_mfma(x, w, b, ksize, variant=0, zmode=0, up2=False):
     """x NCDHW cuda; w, b host tensors.  Returns NCDHW cuda output of the MFMA conv."""
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
+    Zo = Z - 2 if (ksize == 3 and zmode == 2) else Z
+    So = 2 * S if up2 else S
     xc = to_cb8(x)
-    yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
+    yc = torch.zeros((N, (Cout + 7) // 8, Zo, So, So, 8), dtype=torch.float32, device=x.device)
     wh, bh = w.contiguous().float(), b.contiguous().float()
     _lib.check(_lib.lib().tm_op_conv_mfma(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
-                                          N, Cin, Cout, Z, S, ksize, variant, _lib.current_stream_ptr()), "tm_op_conv_mfma")
+                                          N, Cin, Cout, Z, S, ksize, zmode, int(up2), variant, _lib.current_stream_ptr()),
+               "tm_op_conv_mfma")
     return from_cb8(yc, Cout), yc
 
 
