@@ -111,3 +111,25 @@ def test_gene_attention_maps():
     # softmax probabilities ~1/229: absolute 1e-7 is ~2e-5 relative
     assert torch.allclose(a.cpu(), ref_a, atol=1e-7, rtol=1e-4), util.report("attn", a, ref_a)
     assert torch.allclose(a.sum(-1).cpu(), torch.ones(4, 3, 229), atol=1e-5)
+
+
+def test_arena_view_and_single_rank_process_group():
+    """model.arena() is a zero-copy uint8 view of the packed weights (what rank 0 broadcasts over
+    RCCL in place of DDP's parameter broadcast, test_brn.py:149); exercised on a 1-rank nccl group."""
+    import torch.distributed as dist
+    m = hip_model()
+    a = m.arena()
+    assert a.dtype == torch.uint8 and a.is_cuda and a.numel() > 850e6
+    before = a[:4096].clone()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        dist.broadcast(a, src=0)
+        dist.barrier()
+        t = torch.tensor([1.5], dtype=torch.float64, device=DEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t) == 1.5
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(a[:4096], before)
