@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 B_IMAGES, P, T_STEPS = 32, 1, 50
 NEEDED_GFLOP_PER_PATCH_STEP = 320.1   # SURVEY.md section 8(d), P=1 (whole path, 2*MAC)
 
@@ -85,6 +86,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline); bf16 = config-4 arithmetic (bf16 3x3x3 convs)")
+    ap.add_argument("--tile", action="store_true",
+                    help="mode-B workload instead: one test_brn tile (25 z-chunks x 5x5 patches, P=4, DDIM) per step")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "conv27_traffic.json"),
                     help="optional rocprofv3 --pmc derived HBM bytes per conv27_mfma launch")
     args = ap.parse_args()
@@ -110,7 +115,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = PathConfig(gen_type="ddpm", batch_size=B_IMAGES)
+    global B_IMAGES, P
+    gen = "ddpm"
+    if args.tile:
+        B_IMAGES, P, gen = 25, 4, "ddim"
+    cfg = PathConfig(gen_type=gen, batch_size=B_IMAGES, compute_dtype=args.dtype)
     log("generating hashed weights")
     sd = hashed_state_dict(cfg, 0)
     log("packing + uploading weights")
@@ -118,14 +127,14 @@ def main():
     log("model ready")
     if world > 1:      # replaces DDP's construction-time parameter broadcast (test_brn.py:149)
         dist.broadcast(model.arena(), src=0)
-    smp = SpacedDiffusionBeatGans(T_STEPS, "ddpm")
+    smp = SpacedDiffusionBeatGans(T_STEPS, gen)
 
     b, C, ps = B_IMAGES, cfg.in_channels, cfg.patch_size
     ne = b * (P + 1) ** 2
     seed = 100 + rank
     img = synth.normal("bench/xT", (b, C, ps * P, ps * P), seed).to(dev)
     rna = synth.gene_counts("bench/rna", (ne, cfg.gn_sz, cfg.gn_sz, cfg.rna_slc * 500), seed).to(dev)
-    noise = [synth.normal(f"bench/nz{k}", (ne, C, ps, ps), seed).to(dev) for k in range(4)]
+    noise = [synth.normal(f"bench/nz{k}", (ne, C, ps, ps), seed).to(dev) for k in range(4)] if gen == "ddpm" else None
     shape_only = torch.empty((b, C, ps * P, ps * P), device="meta")
     tmap = torch.tensor(smp.timestep_map, dtype=torch.int64, device=dev)
 
@@ -134,7 +143,7 @@ def main():
         xp = pad_patchify(state, ps)
         t = tmap[i].expand(b).contiguous()
         eps = model(x=xp, t=t, rna=rna, imgs=shape_only, patch_size=ps).pred
-        return sampler_step(smp, i, xp, eps, noise[k % 4], b, P, P)
+        return sampler_step(smp, i, xp, eps, noise[k % 4] if gen == "ddpm" else None, b, P, P)
 
     state = img
     log("inputs resident; warm-up")
@@ -162,12 +171,13 @@ def main():
     assert torch.isfinite(state).all(), "non-finite state"
 
     if rank == 0:
-        units = b * args.steps * world
+        units = b * P * P * args.steps * world
         value = units / dt
         avg_ms = prof["total_ms"] / max(1, prof["launches"])
         achieved = prof["nominal_flops"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] else 0.0
         traffic = None
-        if os.path.exists(args.pmc_json):
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        if os.path.exists(args.pmc_json) and args.dtype == "f32" and not args.tile:
             try:
                 traffic = json.load(open(args.pmc_json)).get("hbm_bytes_per_launch")
             except Exception:
@@ -176,23 +186,26 @@ def main():
             "metric": "denoising steps/sec on 64x64x(2 stains x 2 z) patches (interior patch-steps/s)",
             "value": round(value, 3), "unit": "interior patch-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (hashed weights seed 0, N(0,1) state/noise, sparse integer gene counts)",
-            "config": {"workload": "configs[1]: b=32 images x 1 interior 64x64 patch (P=1, 128 padded + 32 collage "
-                                   "patches/step), rna_slc=4, rna_num=229, stain=all, DDPM T=50 schedule, fp32, "
-                                   "mode A (pad+patchify -> UNet -> DDPM update)",
-                       "per_gpu_patches_per_step": b, "parallelism": f"dp{world} (independent patch batches)"},
+            "config": {"workload": ("configs[1]: b=32 images x 1 interior 64x64 patch (P=1, 128 padded + 32 collage "
+                                    "patches/step), rna_slc=4, rna_num=229, stain=all, DDPM T=50 schedule, fp32, "
+                                    "mode A (pad+patchify -> UNet -> DDPM update)") if not args.tile else
+                                   ("one test_brn tile per step: 25 z-chunks x (5x5 padded -> 4x4 interior) patches "
+                                    "(P=4, 625 padded + 400 collage patches), DDIM T=50 schedule, mode B arithmetic"),
+                       "per_gpu_patches_per_step": b * P * P, "parallelism": f"dp{world} (independent patch batches)"},
             "full_50_step_patches_per_s": round(value / T_STEPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "conv27_mfma (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": ("conv3d_mfma<2,*,*> (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
+                                                      else "conv27_bf16 (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x16_bf16)"),
+                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "launches_timed": prof["launches"], "launches_per_step": prof["launches"] // max(1, args.steps),
                          "avg_launch_ms": round(avg_ms, 4),
                          "nominal_gflop_per_launch": round(prof["nominal_flops"] / max(1, prof["launches"]) / 1e9, 3),
                          "executed_mfma_tflops": round(prof["executed_flops"] / (prof["total_ms"] * 1e-3) / 1e12, 3) if prof["total_ms"] else 0.0,
                          "alg_gbytes_per_s": round(prof["alg_bytes"] / (prof["total_ms"] * 1e-3) / 1e9, 1) if prof["total_ms"] else 0.0,
                          "conv27_share_of_step_time": round(prof["total_ms"] / (1e3 * dt), 4),
-                         "whole_step_needed_tflops": round(NEEDED_GFLOP_PER_PATCH_STEP * value / world / 1e3, 3)},
+                         "whole_step_needed_tflops": round((NEEDED_GFLOP_PER_PATCH_STEP if P == 1 else 202.6) * value / world / 1e3, 3)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)

@@ -37,7 +37,11 @@ enum {
   TM_ERR_WORKSPACE = -5   /* workspace too small */
 };
 
-enum { TM_DTYPE_F32 = 0 };
+/* TM_DTYPE_F32: every kernel computes in fp32 (exact-fp32 MFMA).  TM_DTYPE_BF16: the 3x3x3 convs
+ * (95 % of the FLOPs) take bf16 weights and bf16 normalised/activated inputs on the bf16 MFMA with
+ * fp32 accumulation; the residual stream, norms, attention and everything else stay fp32.
+ * Parameters are always loaded as fp32 and rounded (RNE) when packed. */
+enum { TM_DTYPE_F32 = 0, TM_DTYPE_BF16 = 1 };
 enum { TM_SAMPLE_DDPM = 0, TM_SAMPLE_DDIM = 1 };
 
 /* Model configuration.  Replaces BeatGANsUNetConfig as filled by
@@ -53,7 +57,7 @@ typedef struct tm_config {
   int32_t attn_res;       /* attention_resolutions[0]: 16 */
   int32_t num_res_blocks; /* 2 */
   int32_t vis_only;       /* 1: attention-map model (model/unet_attn.py), time_embed + rna_blocks[0] */
-  int32_t dtype;          /* TM_DTYPE_F32 */
+  int32_t dtype;          /* TM_DTYPE_F32 | TM_DTYPE_BF16 (compute type of the 3x3x3 convs) */
 } tm_config;
 
 typedef struct tm_model tm_model;
@@ -171,6 +175,11 @@ int tm_op_from_cb8(const void* x_cb8, void* y_ncdhw, int N, int C, int Z, int H,
 int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
                     int N, int Cin, int Cout, int Z, int S, int ksize, int zmode, int up2,
                     int tile_variant, void* stream);
+
+/* bf16 variant of the 3x3x3 pad-1 conv (Z == 2): x fp32 CB8 is rounded to bf16 (RNE) on the device,
+ * w rounded on the host; fp32 accumulate, fp32 CB8 output. */
+int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
+                      int N, int Cin, int Cout, int S, void* stream);
 
 /* Generic direct Conv3d (stem / head / RNA path), NCDHW in, NCDHW out. */
 int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N,

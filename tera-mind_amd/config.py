@@ -38,6 +38,9 @@ class PathConfig:
     gen_type: str = "ddpm"              # 'ddpm' | 'ddim'
     fp16: bool = True                   # reference autocast flag (inert on CPU)
     batch_size: int = 1
+    # arithmetic type of the 3x3x3 convs: "f32" (exact-fp32 MFMA) or "bf16" (bf16 MFMA, fp32 accumulate;
+    # BASELINE config 4).  Not part of the checkpoint name.
+    compute_dtype: str = field(default="f32", compare=False)
     name: str = field(default="", compare=False)
 
     def __post_init__(self):
@@ -45,6 +48,8 @@ class PathConfig:
             raise NotImplementedError("Patch size not in [32, 64, 128]")
         if self.rna_slc not in DOWN_Z_KERNEL:
             raise ValueError(f"rna_slc {self.rna_slc} not in {sorted(DOWN_Z_KERNEL)}")
+        if self.compute_dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute_dtype {self.compute_dtype!r}")
         if self.stain not in ("DAPI", "PolyT", "all"):
             raise ValueError(f"stain {self.stain!r}")
         if not self.name:

@@ -1,0 +1,261 @@
+// bf16 variant of the 3x3x3 implicit-GEMM conv (BASELINE config 4: bf16 weights / conv inputs,
+// fp32 accumulate, fp32 residual stream).
+//
+//   D[cout 32][voxel 32] += W[cout 32][k 16] * X[k 16][voxel 32]      v_mfma_f32_32x32x16_bf16
+//
+// One MFMA contracts a PAIR of 8-channel blocks for one tap: lanes 0-31 carry block 2p, lanes
+// 32-63 block 2p+1 (8 bf16 = one 16-byte ds_read_b128 per operand per lane).  The LDS images are
+// byte-for-byte the shape of the fp32 kernel's ([tap][cout][32 B], [voxel][32 B]) but hold twice
+// the channels, and an MFMA retires them 16x faster -- so the design point moves from "keep the
+// matrix pipe fed with instructions" to "amortise the staged bytes":
+//   * 8 waves, wave tile 64 cout x 128 voxels (2 x 4 MFMA tiles, 128 accumulator VGPRs),
+//     workgroup tile 128 x 512 (Cout >= 128) or 64 x 1024 (Cout = 64): 12 B/clk/CU of staging
+//     instead of 25 for the fp32 tile shape;
+//   * a stage is one (channel-block pair, input plane): 9 taps, weights 9 x TN x 32 B, halo tile
+//     of ONE plane; two LDS buffers, next stage's global loads are in flight during the MFMAs,
+//     one barrier per stage;
+//   * packed weights carry the 16-byte slot swap for couts with bit 3 set that makes the
+//     ds_read_b128 of the weight fragment bank-conflict free (cdna guide T2 / microarch LDS table).
+// Same operand orientation (weight = A, activation = B) and epilogue as conv3d_mfma.
+#include "tm_device.h"
+
+#include <string.h>
+
+namespace tmk {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector (HIP's uint4 class resists SROA)
+
+struct ConvArgsH {
+  ConvArgs c;                 // x / w are reinterpreted: x = bf16 CB8 (elements), w = bf16 packed
+  long x_nstride_e, x_plane_e;   // in bf16 elements
+  int Cbp;                    // channel-block pairs
+};
+
+template <int TN, int TW>
+struct HGeo {
+  static constexpr int WNW = TN / 64;                 // waves along cout
+  static constexpr int WMW = 8 / WNW;                 // waves along voxels
+  static constexpr int TM = WMW * 128;                // voxels per workgroup
+  static constexpr int TR = (TM / TW < TW) ? (TM / TW) : TW;
+  static constexpr int NPB = TM / (TR * TW);
+  static constexpr int HR = TR + 2, HC = TW + 2;
+  static constexpr int XV = NPB * HR * HC;            // halo voxels of ONE input plane
+  static constexpr int XPIECES = XV * 2;
+  static constexpr int PX = (XPIECES + 511) / 512;
+  static constexpr int WPIECES = 9 * TN * 2;
+  static constexpr int PW = (WPIECES + 511) / 512;
+  static constexpr int BUF16 = WPIECES + XPIECES;     // 16-byte units per LDS buffer
+  static constexpr int LDS_BYTES = 2 * BUF16 * 16;
+};
+
+template <int TN, int TW>
+__global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
+  using G = HGeo<TN, TW>;
+  const ConvArgs& a = ah.c;
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int wn = wv % G::WNW, wm = wv / G::WNW;
+
+  const int S = a.S;
+  const int tiles_c = S / TW, tiles_r = S / G::TR;
+  const int tiles = tiles_c * tiles_r;
+  const int bid = blockIdx.x;
+  const int nt = bid % a.ntile;                        // n-tile of TN couts
+  int mt_ = bid / a.ntile;
+  const int pg = mt_ / (2 * tiles);
+  mt_ -= pg * 2 * tiles;
+  const int zo = mt_ / tiles;
+  mt_ -= zo * tiles;
+  const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
+
+  const __bf16* xg = (const __bf16*)a.x;
+  const __bf16* wg = (const __bf16*)a.w;
+
+  // ---- staging descriptors ----
+  long xoff[G::PX];
+#pragma unroll
+  for (int k = 0; k < G::PX; ++k) {
+    const int i = tid + k * 512;
+    long off = -1;
+    if (i < G::XPIECES) {
+      const int half = i & 1;
+      int v = i >> 1;
+      const int hc = v % G::HC; v /= G::HC;
+      const int hr = v % G::HR;
+      const int ps = v / G::HR;
+      const int n = pg * G::NPB + ps;
+      const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
+      if (n < a.N && y >= 0 && y < S && x >= 0 && x < S)
+        off = (long)n * ah.x_nstride_e + (long)half * ah.x_plane_e + ((long)y * S + x) * 8;
+    }
+    xoff[k] = off;
+  }
+  // packed weights: [n-tile][pair][kz 3][9 taps][TN][2][8]
+  const __bf16* wsrc = wg + (long)nt * ah.Cbp * 27 * TN * 16 + (long)tid * 8;
+
+  // ---- fragment addresses (16-byte units inside a buffer) ----
+  int xb[4], on[4], ooff[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int v = (wm * 4 + mt) * 32 + i32;
+    const int ps = v / (G::TR * TW);
+    const int rem = v - ps * (G::TR * TW);
+    const int r = rem / TW, c = rem - r * TW;
+    xb[mt] = G::WPIECES + ((ps * G::HR + r) * G::HC + c) * 2 + h;
+    const int n = pg * G::NPB + ps;
+    on[mt] = n;
+    const int y = tr * G::TR + r, x = tc * TW + c;
+    ooff[mt] = (n < a.N) ? ((zo * S + y) * S + x) * 8 : -1;
+  }
+  const int wb = (wn * 64 + i32) * 2 + (h ^ ((i32 >> 3) & 1));
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
+
+  u32x4 xr[G::PX], wr[G::PW];
+  const u32x4 zero16 = {0u, 0u, 0u, 0u};
+  auto load_stage = [&](int hs) {
+    const int cbp = hs >> 1, zi = hs & 1;
+    const __bf16* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
+#pragma unroll
+    for (int k = 0; k < G::PX; ++k) xr[k] = (xoff[k] >= 0) ? *(const u32x4*)(xp + xoff[k]) : zero16;
+    const __bf16* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k)
+      wr[k] = (G::WPIECES % 512 == 0 || tid + k * 512 < G::WPIECES) ? *(const u32x4*)(wp + (long)k * 512 * 8) : zero16;
+  };
+  auto store_stage = [&](int buf) {
+    u32x4* base = lds16 + buf * G::BUF16;
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k)
+      if (G::WPIECES % 512 == 0 || tid + k * 512 < G::WPIECES) base[tid + k * 512] = wr[k];
+#pragma unroll
+    for (int k = 0; k < G::PX; ++k)
+      if (tid + k * 512 < G::XPIECES) base[G::WPIECES + tid + k * 512] = xr[k];
+  };
+
+  const int NH = 2 * ah.Cbp;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int hs = 0; hs < NH; ++hs) {
+    if (hs + 1 < NH) load_stage(hs + 1);
+    const u32x4* buf = lds16 + (hs & 1) * G::BUF16;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tap = ky * 3 + kx;
+        const int xd = (ky * G::HC + kx) * 2;
+        bf16x8 wf[2], xf[4];
+        {
+          wf[0] = __builtin_bit_cast(bf16x8, buf[tap * TN * 2 + wb]);
+          wf[1] = __builtin_bit_cast(bf16x8, buf[tap * TN * 2 + 64 + wb]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          xf[mt] = __builtin_bit_cast(bf16x8, buf[xb[mt] + xd]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct], xf[mt], acc[ct][mt], 0, 0, 0);
+      }
+    }
+    if (hs + 1 < NH) store_stage((hs + 1) & 1);
+    __syncthreads();
+  }
+  conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 2 * S);
+}
+
+// ------------------------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+int conv_bf16_tn(int Cout) { return Cout <= 64 ? 64 : 128; }
+
+size_t conv_bf16_pack_elems(int Cout, int Cbi) {
+  const int TN = conv_bf16_tn(Cout);
+  const int ntile = (Cout + TN - 1) / TN, Cbp = (Cbi + 1) / 2;
+  return (size_t)ntile * Cbp * 27 * TN * 16;
+}
+
+void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out) {
+  int Cin = 0, Cbi = 0;
+  for (int s = 0; s < nseg; ++s) { Cin += seg_c[s]; Cbi += (seg_c[s] + 7) / 8; }
+  const int TN = conv_bf16_tn(Cout), Cbp = (Cbi + 1) / 2;
+  memset(out, 0, conv_bf16_pack_elems(Cout, Cbi) * sizeof(uint16_t));
+  int ci0 = 0, cb0 = 0;
+  for (int s = 0; s < nseg; ++s) {
+    for (int c = 0; c < seg_c[s]; ++c) {
+      const int ci = ci0 + c, cb = cb0 + c / 8, c8 = c % 8;
+      const int pair = cb >> 1, half = cb & 1;
+      for (int co = 0; co < Cout; ++co) {
+        const int nt = co / TN, col = co % TN;
+        const int slot = half ^ ((col >> 3) & 1);                 // bank-conflict-free weight fragment reads
+        const float* src = w + ((size_t)co * Cin + ci) * 27;
+        uint16_t* dst = out + ((((size_t)nt * Cbp + pair) * 27) * TN + col) * 16 + slot * 8 + c8;
+        for (int t = 0; t < 27; ++t) dst[(size_t)t * TN * 16] = f32_to_bf16_rne(src[t]);
+      }
+    }
+    ci0 += seg_c[s];
+    cb0 += (seg_c[s] + 7) / 8;
+  }
+}
+
+hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
+  ConvArgsH ah;
+  ConvArgs& a = ah.c;
+  a.x = (const float*)L.x.p; a.x_nstride = 0; a.x_plane = 0;
+  a.w = (const float*)L.w; a.bias = L.bias;
+  a.y = L.y.p; a.y_nstride = L.y.nstride; a.y_plane = L.y.plane(); a.Cob = L.y.Cb;
+  a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
+  a.gate = nullptr; a.gate_nstride = 0;
+  a.N = L.x.N; a.S = L.x.H; a.Z = 2; a.Cbi = L.x.Cb; a.flags = 0;
+  ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
+  if (L.x.Cb & 1 || L.x.Z != 2 || L.y.Z != 2 || L.x.H != L.x.W || L.y.H != L.x.H || L.y.N != L.x.N)
+    return hipErrorInvalidValue;
+  const int S = a.S, TN = conv_bf16_tn(L.Cout);
+  a.ntile = (L.Cout + TN - 1) / TN;
+  if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
+  if (S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
+#define TM_LAUNCHH(TN_, TW_)                                                                     \
+  do {                                                                                          \
+    using G = HGeo<TN_, TW_>;                                                                   \
+    static bool attr_done = false;                                                              \
+    if (!attr_done) {                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_>,                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_done = true;                                                                         \
+    }                                                                                           \
+    const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
+    const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
+    const long grid = pgs * 2 * tiles * a.ntile;                                                \
+    hipLaunchKernelGGL((conv27_bf16<TN_, TW_>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
+  } while (0)
+  if (TN == 64) {
+    if (S >= 32) TM_LAUNCHH(64, 32); else if (S == 16) TM_LAUNCHH(64, 16); else TM_LAUNCHH(64, 8);
+  } else {
+    if (S >= 32) TM_LAUNCHH(128, 32); else if (S == 16) TM_LAUNCHH(128, 16); else TM_LAUNCHH(128, 8);
+  }
+#undef TM_LAUNCHH
+  return hipGetLastError();
+}
+
+}  // namespace tmk

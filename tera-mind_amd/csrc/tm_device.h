@@ -1,0 +1,102 @@
+// Device-side helpers shared by the kernel translation units (not part of the public ABI).
+#pragma once
+#include "tm_kernels.h"
+#include <math.h>
+
+namespace tmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TM_EPS 1e-6f
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float kBeta = 0.7978845608028654f;   // sqrt(2/pi)
+  const float kKappa = 0.044715f;
+  float inner = kBeta * (x + kKappa * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ==========================================================================================
+// Conv3d as implicit GEMM on the fp32 MFMA.
+//   D[cout 32][voxel 32] += W[cout 32][k 2] * X[k 2][voxel 32]   (v_mfma_f32_32x32x2_f32)
+// The weight is the A operand and the activation the B operand, so that each lane ends up
+// with 4 consecutive couts of ONE voxel per accumulator quad: the CB8 store is a coalesced
+// float4 per lane (32 voxels x 32 B contiguous per wave instruction).
+// One ds_read_b128 of 4 channels feeds 4 MFMAs: lanes 0-31 carry channels {0..3}, lanes
+// 32-63 channels {4..7} of the 8-channel block, identically for W and X, so MFMA #kk
+// contracts channels {kk, 4+kk}.
+//
+// Replaces nn.Conv3d(k=3, padding=1) of ResBlock (reference model/MBAblocks.py:146-148,
+// 182-186).  Z is 2 there, so for every output plane one of the three z taps only ever
+// multiplies zero padding: a workgroup owns ONE output plane zo and runs 18 of the 27 taps
+// (input planes zi = 0,1 with kz = zi + 1 - zo).
+// ==========================================================================================
+struct ConvArgs {
+  const float* x; long x_nstride; long x_plane;
+  const float* w; const float* bias;
+  float* y; long y_nstride; long y_plane; int Cob;
+  const float* res; long res_nstride;
+  const float* gate; long gate_nstride;
+  int N, S, Z, Cbi, ntile, flags;
+};
+
+template <int WM>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][WM], int nt, int h,
+                                              const int (&on)[WM], const int (&ooff)[WM], int S_out) {
+  // ooff: in-plane float offset of the voxel in the OUTPUT plane geometry (or -1)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cob = nt * 8 + ct * 4 + g;
+      if (cob >= a.Cob) continue;
+      const f32x4 bv = *(const f32x4*)(a.bias + (long)cob * 8 + 4 * h);
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) {
+        if (ooff[mt] < 0) continue;
+        f32x4 o;
+        o[0] = acc[ct][mt][4 * g + 0] + bv[0];
+        o[1] = acc[ct][mt][4 * g + 1] + bv[1];
+        o[2] = acc[ct][mt][4 * g + 2] + bv[2];
+        o[3] = acc[ct][mt][4 * g + 3] + bv[3];
+        if (a.flags & EPI_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_f(o[j]);
+        }
+        const long pl = (long)cob * a.y_plane + ooff[mt] + 4 * h;
+        if (a.gate) {
+          const f32x4 gv = *(const f32x4*)(a.gate + (long)on[mt] * a.gate_nstride + pl);
+          o *= gv;
+        }
+        if (a.res) {
+          const f32x4 rv = *(const f32x4*)(a.res + (long)on[mt] * a.res_nstride + pl);
+          o = rv + o;
+        }
+        float* yp = a.y + (long)on[mt] * a.y_nstride + pl;
+        if (a.flags & EPI_UP2) {
+          // nearest x2 on (H, W): ooff already addresses (2y, 2x) of the 2S plane
+          *(f32x4*)(yp) = o;
+          *(f32x4*)(yp + 8) = o;
+          *(f32x4*)(yp + (long)S_out * 8) = o;
+          *(f32x4*)(yp + (long)S_out * 8 + 8) = o;
+        } else {
+          *(f32x4*)(yp) = o;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tmk

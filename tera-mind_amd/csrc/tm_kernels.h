@@ -51,6 +51,25 @@ struct ConvLaunch {
 };
 hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s);
 
+// ---- bf16 3x3x3 conv (tm_conv_bf16.hip) --------------------------------------------------
+struct TVH {                        // bf16 CB8 tensor [N][Cb (even)][Z][H][W][8]; strides in elements
+  uint16_t* p = nullptr;
+  int N = 0, C = 0, Cb = 0, Z = 0, H = 0, W = 0;
+  long nstride = 0;
+};
+struct ConvLaunchH {
+  TVH x;
+  const uint16_t* w = nullptr;      // packed by conv_bf16_pack_host
+  const float* bias = nullptr;      // [ceil(Cout/64)*64] fp32
+  int Cout = 0;
+  TV y;                             // fp32 CB8 output
+  const TV* res = nullptr;
+};
+int conv_bf16_tn(int Cout);
+size_t conv_bf16_pack_elems(int Cout, int Cbi);
+void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
+hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s);
+
 // ---- prep: concat + resample + RMSNorm(C) * w -> modulate -> act ---------------------
 struct PrepSrc {
   const float* p = nullptr;
@@ -78,6 +97,9 @@ struct PrepLaunch {
   long out_nstride = 0;
   float* raw = nullptr;             // optional un-normalised (resampled, concatenated) copy
   long raw_nstride = 0;
+  uint16_t* out_h = nullptr;        // bf16 output instead of `out` (conv27_bf16 input), nstride in elements
+  long out_h_nstride = 0;
+  int pad_blocks = 0;               // extra all-zero channel blocks appended to the bf16 output (pair padding)
 };
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
 

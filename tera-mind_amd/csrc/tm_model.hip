@@ -47,6 +47,7 @@ struct ResW {
   ConvW c1, c2, skip;
   const float* n1 = nullptr;  // [cbi*8] virtual order
   const float* n2 = nullptr;  // [cout]
+  const uint16_t *c1h = nullptr, *c2h = nullptr;   // bf16 packed 3x3x3 weights (TM_DTYPE_BF16)
   int emb_off = 0;
 };
 struct AttnW {
@@ -266,7 +267,7 @@ extern "C" const char* tm_last_error(void) { return g_err; }
 
 extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
   if (!cfg || !out) return fail(TM_ERR_ARG, "null argument");
-  if (cfg->dtype != TM_DTYPE_F32) return fail(TM_ERR_ARG, "only TM_DTYPE_F32 is implemented");
+  if (cfg->dtype != TM_DTYPE_F32 && cfg->dtype != TM_DTYPE_BF16) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_F32 or TM_DTYPE_BF16");
   if (cfg->patch_size != 64 || cfg->rna_slc != 4)
     return fail(TM_ERR_ARG, "only patch_size=64, rna_slc=4 (checkpoint config) is implemented, got %d/%d",
                 cfg->patch_size, cfg->rna_slc);
@@ -327,6 +328,7 @@ struct Packer {
   }
 };
 struct Fix { const float** slot; size_t off; };
+struct FixH { const uint16_t** slot; size_t off; };   // offsets in floats into the same arena
 
 static const std::vector<float>& P(tm_model* m, const std::string& k) { return m->host[k].data; }
 
@@ -338,6 +340,22 @@ static void pack_conv(tm_model* m, Packer& pk, std::vector<Fix>& fx, ConvW& cw, 
   size_t off = pk.reserve(conv_pack_floats(Cout, cbi, taps));
   conv_pack_host(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(), taps, pk.buf.data() + off);
   fx.push_back({&cw.w, off});
+  size_t boff = pk.reserve((size_t)cw.ntile * 64);
+  const std::vector<float>& b = P(m, bkey);
+  for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
+  fx.push_back({&cw.bias, boff});
+}
+// 3x3x3 conv for the bf16 path: bf16 packed weights (tm_conv_bf16.hip layout) + the fp32 bias
+static void pack_conv_h(tm_model* m, Packer& pk, std::vector<Fix>& fx, std::vector<FixH>& fxh, ConvW& cw,
+                        const uint16_t** wslot, const std::string& wkey, const std::string& bkey, int Cout,
+                        const std::vector<int>& seg) {
+  int cbi = 0;
+  for (int c : seg) cbi += (c + 7) / 8;
+  cw.Cout = Cout; cw.Cbi = cbi; cw.taps = 27; cw.ntile = (Cout + 63) / 64; cw.w = nullptr;
+  const size_t elems = conv_bf16_pack_elems(Cout, cbi);
+  size_t off = pk.reserve((elems + 1) / 2);
+  conv_bf16_pack_host(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(), (uint16_t*)(pk.buf.data() + off));
+  fxh.push_back({wslot, off});
   size_t boff = pk.reserve((size_t)cw.ntile * 64);
   const std::vector<float>& b = P(m, bkey);
   for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
@@ -405,6 +423,8 @@ extern "C" int tm_model_finalize(tm_model* m) {
   const tm_config& c = m->cfg;
   Packer pk;
   std::vector<Fix> fx;
+  std::vector<FixH> fxh;
+  const bool bf16 = c.dtype == TM_DTYPE_BF16;
   pack_raw(pk, fx, &m->te_w1, P(m, "time_embed.time_embed.0.weight"));
   pack_raw(pk, fx, &m->te_b1, P(m, "time_embed.time_embed.0.bias"));
   pack_raw(pk, fx, &m->te_w2, P(m, "time_embed.time_embed.2.weight"));
@@ -447,8 +467,13 @@ extern "C" int tm_model_finalize(tm_model* m) {
       fx.push_back({&m->emb_b, boff});
     }
     for (ResW& r : m->res) {
-      pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27);
-      pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27);
+      if (bf16) {
+        pack_conv_h(m, pk, fx, fxh, r.c1, &r.c1h, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg);
+        pack_conv_h(m, pk, fx, fxh, r.c2, &r.c2h, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout});
+      } else {
+        pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27);
+        pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27);
+      }
       if (r.has_skip)
         pack_conv(m, pk, fx, r.skip, r.pfx + ".skip_connection.weight", r.pfx + ".skip_connection.bias", r.cout, r.seg, 1);
       pack_vec(pk, fx, &r.n1, P(m, r.pfx + ".in_layers.0.weight"), r.seg);
@@ -472,6 +497,7 @@ extern "C" int tm_model_finalize(tm_model* m) {
   HIP_TRY(hipMalloc((void**)&m->arena, m->arena_floats * sizeof(float)));
   HIP_TRY(hipMemcpy(m->arena, pk.buf.data(), m->arena_floats * sizeof(float), hipMemcpyHostToDevice));
   for (Fix& f : fx) *f.slot = m->arena + f.off;
+  for (FixH& f : fxh) *f.slot = (const uint16_t*)(m->arena + f.off);
   m->host.clear();
   m->finalized = true;
   return TM_OK;
@@ -538,6 +564,13 @@ struct Ctx {
     t.p = alloc_f((size_t)N * t.nstride);
     return t;
   }
+  TVH tensor_h(int N, int Cb_even, int Z, int S) {           // bf16 CB8 (conv27_bf16 input)
+    TVH t;
+    t.N = N; t.Cb = Cb_even; t.C = Cb_even * 8; t.Z = Z; t.H = S; t.W = S;
+    t.nstride = (long)Cb_even * Z * S * S * 8;
+    t.p = (uint16_t*)alloc_f(((size_t)N * t.nstride + 1) / 2);
+    return t;
+  }
   void check(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
@@ -588,6 +621,30 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
   }
 }
 
+static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, int cin_real) {
+  if (cx.dry) return;
+  ConvLaunchH L;
+  L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res;
+  tm_model* m = cx.m;
+  const bool prof = m->prof_on;
+  if (prof) {
+    if (m->prof_used == m->prof_ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { cx.check(hipErrorOutOfMemory); return; }
+      m->prof_ev.emplace_back(a, b);
+    }
+    cx.check(hipEventRecord(m->prof_ev[m->prof_used].first, cx.s));
+  }
+  cx.check(launch_conv27_bf16(L, cx.s));
+  if (prof) {
+    cx.check(hipEventRecord(m->prof_ev[m->prof_used].second, cx.s));
+    m->prof_used++;
+    const double vox = (double)x.N * x.Z * x.H * x.W;
+    m->prof_nominal += 2.0 * cin_real * cw.Cout * 27.0 * vox;
+    m->prof_bytes += 2.0 * vox * x.Cb * 8 + 2.0 * (double)conv_bf16_pack_elems(cw.Cout, cw.Cbi) + 4.0 * vox * y.Cb * 8;
+  }
+}
+
 // ResBlock._forward (model/MBAblocks.py:237-299)
 static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, int per_image, int S_out, int mode,
                     TV* out_opt) {
@@ -596,8 +653,11 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   TV out = out_opt ? *out_opt : cx.tensor(N, w.cout, Z, S_out);
   const size_t mark = cx.top;
   int cin_pad = w.cbi * 8;
-  TV A = cx.tensor(N, cin_pad, Z, S_out);
-  TV raw;
+  const bool bf16 = m->cfg.dtype == TM_DTYPE_BF16;
+  TV A, raw, H1, A2;
+  TVH Ah, A2h;
+  if (bf16) Ah = cx.tensor_h(N, (w.cbi + 1) / 2 * 2, Z, S_out);
+  else A = cx.tensor(N, cin_pad, Z, S_out);
   // the residual / skip-conv input is the CONCATENATED (and resampled) x, MBAblocks.py:252-258,297:
   // it equals a stored tensor only for a single plain source
   const bool need_raw = w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage;
@@ -611,13 +671,16 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     }
     P.resample = mode; P.N = N; P.Z = Z; P.S = S_out; P.p1 = cx.p1; P.p2 = cx.p2;
     P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
-    P.out = A.p; P.out_nstride = A.nstride;
+    if (bf16) { P.out_h = Ah.p; P.out_h_nstride = Ah.nstride; P.pad_blocks = Ah.Cb - w.cbi; }
+    else { P.out = A.p; P.out_nstride = A.nstride; }
     if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
     cx.check(launch_prep(P, cx.s));
   }
-  TV H1 = cx.tensor(N, w.cout, Z, S_out);
-  run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
-  TV A2 = cx.tensor(N, w.cout, Z, S_out);
+  H1 = cx.tensor(N, w.cout, Z, S_out);
+  if (bf16) run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin);
+  else run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
+  if (bf16) A2h = cx.tensor_h(N, (w.cout / 8 + 1) / 2 * 2, Z, S_out);
+  else A2 = cx.tensor(N, w.cout, Z, S_out);
   if (!cx.dry) {
     PrepLaunch P;
     P.nsrc = 1;
@@ -626,8 +689,18 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
     P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
     P.mod_stride = m->emb_tot;
-    P.out = A2.p; P.out_nstride = A2.nstride;
+    if (bf16) { P.out_h = A2h.p; P.out_h_nstride = A2h.nstride; P.pad_blocks = A2h.Cb - w.cout / 8; }
+    else { P.out = A2.p; P.out_nstride = A2.nstride; }
     cx.check(launch_prep(P, cx.s));
+  }
+  if (bf16) {
+    const TV* r = nullptr;
+    if (w.has_skip) { run_conv(cx, raw, w.skip, out, nullptr, nullptr, 0); r = &out; }
+    else if (need_raw) r = &raw;
+    else r = &src[0].t;
+    run_conv_h(cx, A2h, w.c2h, w.c2, out, r, w.cout);
+    cx.top = mark;
+    return out;
   }
   if (w.has_skip) {
     run_conv(cx, raw, w.skip, out, nullptr, nullptr, 0);
@@ -927,6 +1000,41 @@ extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void
   (void)hipFree(dw); (void)hipFree(db);
   if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv_mfma: %s", hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv_mfma execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}
+extern "C" int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
+                                 int Cout, int S, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Cbi = (Cin + 7) / 8, Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64;
+  std::vector<uint16_t> pk(conv_bf16_pack_elems(Cout, Cbi));
+  conv_bf16_pack_host((const float*)w_host, Cout, &Cin, 1, pk.data());
+  std::vector<float> bp((size_t)nt64 * 64, 0.f);
+  memcpy(bp.data(), bias_host, Cout * sizeof(float));
+  uint16_t *dw = nullptr, *dx = nullptr;
+  float* db = nullptr;
+  const long vox = (long)2 * S * S;
+  HIP_TRY(hipMalloc((void**)&dw, pk.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMalloc((void**)&db, bp.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&dx, (size_t)N * Cbe * vox * 8 * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, Cin, 2, S, S);
+  PrepLaunch P;                       // fp32 CB8 -> bf16 CB8 (no norm / act), pair padding
+  P.nsrc = 1;
+  P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+  P.N = N; P.Z = 2; P.S = S;
+  P.out_h = dx; P.out_h_nstride = (long)Cbe * vox * 8; P.pad_blocks = Cbe - Cbi;
+  hipError_t e0 = launch_prep(P, st);
+  ConvLaunchH L;
+  L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = 2; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
+  L.w = dw; L.bias = db; L.Cout = Cout;
+  L.y = view_cb8(y_cb8, N, Cout, 2, S, S);
+  hipError_t e = launch_conv27_bf16(L, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dx);
+  if (e0 != hipSuccess) return fail(TM_ERR_HIP, "launch_prep: %s", hipGetErrorString(e0));
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv27_bf16: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv27_bf16 execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
 extern "C" int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N, int Cin,

@@ -32,7 +32,8 @@ def _tm_config(cfg: PathConfig, vis_only: bool) -> _lib.TmConfig:
     c.net_ch, c.embed_ch, c.attn_res = cfg.net_ch, cfg.embed_ch, cfg.attn_res[0]
     for i, v in enumerate(cfg.ch_mult):
         c.ch_mult[i] = v
-    c.num_res_blocks, c.vis_only, c.dtype = cfg.num_res_blocks, int(vis_only), 0
+    c.num_res_blocks, c.vis_only = cfg.num_res_blocks, int(vis_only)
+    c.dtype = {"f32": 0, "bf16": 1}[cfg.compute_dtype]
     return c
 
 

@@ -110,3 +110,35 @@ def test_conv_validz_mfma_exact_integers(N, Cin, Cout):
     assert torch.equal(got.cpu(), ref), util.report("down_z", got, ref)
     if Cout % 8:
         assert float(raw[:, -1, ..., Cout % 8:].abs().max()) == 0.0
+
+
+BF16_CASES = [(2, 16, 64, 8), (17, 24, 128, 8), (3, 13, 40, 8), (9, 229, 512, 8), (5, 40, 192, 16), (3, 96, 64, 16),
+              (1, 72, 64, 32), (2, 16, 128, 32), (1, 8, 64, 64), (1, 24, 128, 64)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,S", BF16_CASES)
+def test_conv27_bf16_exact_integers(N, Cin, Cout, S):
+    """Small integers are exact in bf16 and their products/sums exact in fp32: bit-exact check of the
+    bf16 MFMA kernel's fragment layout, pair padding, slot swizzle and tiling."""
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 41)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 42)
+    b = util.rand_int((Cout,), -4, 4, 43)
+    ref = F.conv3d(x, w, b, padding=1)
+    got, raw = util.conv27_bf16(x.to(DEV), w, b)
+    assert torch.equal(got.cpu(), ref), util.report("conv27 bf16", got, ref)
+    if Cout % 8:
+        assert float(raw[:, -1, ..., Cout % 8:].abs().max()) == 0.0
+
+
+def test_conv27_bf16_random_vs_bf16_rounded_reference():
+    g = torch.Generator().manual_seed(17)
+    N, Cin, Cout, S = 2, 741, 512, 8
+    x = torch.randn((N, Cin, 2, S, S), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3, 3), generator=g) / (Cin * 27) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    ref = F.conv3d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1)      # same rounded operands, fp32 math
+    got, _ = util.conv27_bf16(x.to(DEV), w, b)
+    assert torch.allclose(got.cpu(), ref, atol=3e-5, rtol=1e-5), util.report("conv27 bf16 random", got, ref)
+    full = F.conv3d(x, w, b, padding=1)
+    rel = ((got.cpu() - full).norm() / full.norm()).item()
+    assert rel < 6e-3, rel                                                          # bf16 operand rounding: ~2^-9 relative
