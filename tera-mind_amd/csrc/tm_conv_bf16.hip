@@ -178,6 +178,127 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 2 * S);
 }
 
+// ---- 1x1x1 conv / Linear on '(z h w) c' tokens, bf16 operands (flat voxel tiles) -----------
+// No tap reuse: staging is 4096*(1/TN + 1/TM) = 40 B/clk/CU at the matrix-pipe rate, so this kernel
+// is L2->LDS bound (~30 % of the bf16 MFMA peak at best), still ~8x the fp32 form.
+template <int TN>
+struct H1Geo {
+  static constexpr int WNW = TN / 64, WMW = 8 / WNW, TM = WMW * 128;
+  static constexpr int KP = 2;                                   // channel-block pairs per stage
+  static constexpr int WPIECES = KP * TN * 2, XPIECES = KP * TM * 2;
+  static constexpr int PW = (WPIECES + 511) / 512, PX = XPIECES / 512;
+  static constexpr int BUF16 = WPIECES + XPIECES;
+  static constexpr int LDS_BYTES = 2 * BUF16 * 16;
+};
+
+template <int TN>
+__global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah) {
+  using G = H1Geo<TN>;
+  const ConvArgs& a = ah.c;
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int wn = wv % G::WNW, wm = wv / G::WNW;
+  const int bid = blockIdx.x;
+  const int nt = bid % a.ntile;
+  const int mtile = bid / a.ntile;
+  const long VPN = (long)a.Z * a.S * a.S, vtot = VPN * a.N;
+  const __bf16* xg = (const __bf16*)a.x;
+  const __bf16* wg = (const __bf16*)a.w;
+
+  long xoff[G::PX];
+  int xkp[G::PX];
+#pragma unroll
+  for (int k = 0; k < G::PX; ++k) {
+    const int i = tid + k * 512;
+    const int half = i & 1;
+    const int v = (i >> 1) % G::TM;
+    xkp[k] = (i >> 1) / G::TM;
+    const long vg = (long)mtile * G::TM + v;
+    long off = -1;
+    if (vg < vtot) {
+      const long n = vg / VPN;
+      off = n * ah.x_nstride_e + (long)half * ah.x_plane_e + (vg - n * VPN) * 8;
+    }
+    xoff[k] = off;
+  }
+  // packed weights: [n-tile][pair][TN][2][8]
+  const __bf16* wsrc = wg + (long)nt * ah.Cbp * TN * 16 + (long)tid * 8;
+
+  int xb[4], on[4], ooff[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int v = (wm * 4 + mt) * 32 + i32;
+    xb[mt] = G::WPIECES + v * 2 + h;
+    const long vg = (long)mtile * G::TM + v;
+    if (vg < vtot) {
+      const long n = vg / VPN;
+      on[mt] = (int)n;
+      ooff[mt] = (int)((vg - n * VPN) * 8);
+    } else { on[mt] = 0; ooff[mt] = -1; }
+  }
+  const int wb = (wn * 64 + i32) * 2 + (h ^ ((i32 >> 3) & 1));
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
+
+  u32x4 xr[G::PX], wr[G::PW];
+  const u32x4 zero16 = {0u, 0u, 0u, 0u};
+  auto load_stage = [&](int st) {
+    const int p0 = st * G::KP;
+#pragma unroll
+    for (int k = 0; k < G::PX; ++k) {
+      const int pr = p0 + xkp[k];
+      xr[k] = (xoff[k] >= 0 && pr < ah.Cbp) ? *(const u32x4*)(xg + (long)pr * 2 * ah.x_plane_e + xoff[k]) : zero16;
+    }
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) {
+      const int i = tid + k * 512;
+      const int pr = p0 + i / (TN * 2);
+      wr[k] = (i < G::WPIECES && pr < ah.Cbp) ? *(const u32x4*)(wsrc + (long)p0 * TN * 16 + (long)k * 512 * 8) : zero16;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    u32x4* base = lds16 + buf * G::BUF16;
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k)
+      if (tid + k * 512 < G::WPIECES) base[tid + k * 512] = wr[k];
+#pragma unroll
+    for (int k = 0; k < G::PX; ++k) base[G::WPIECES + tid + k * 512] = xr[k];
+  };
+
+  const int NS = (ah.Cbp + G::KP - 1) / G::KP;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < NS; ++st) {
+    if (st + 1 < NS) load_stage(st + 1);
+    const u32x4* buf = lds16 + (st & 1) * G::BUF16;
+#pragma unroll
+    for (int kp = 0; kp < G::KP; ++kp) {
+      bf16x8 wf[2], xf[4];
+      wf[0] = __builtin_bit_cast(bf16x8, buf[kp * TN * 2 + wb]);
+      wf[1] = __builtin_bit_cast(bf16x8, buf[kp * TN * 2 + 64 + wb]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xf[mt] = __builtin_bit_cast(bf16x8, buf[xb[mt] + kp * G::TM * 2]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct], xf[mt], acc[ct][mt], 0, 0, 0);
+    }
+    if (st + 1 < NS) store_stage((st + 1) & 1);
+    __syncthreads();
+  }
+  conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 0);
+}
+
 // ------------------------------------------------------------------------------------------
 static inline uint16_t f32_to_bf16_rne(float f) {
   uint32_t u;
@@ -218,6 +339,66 @@ void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, u
   }
 }
 
+size_t conv1_bf16_pack_elems(int Cout, int Cbi) {
+  const int TN = conv_bf16_tn(Cout);
+  return (size_t)((Cout + TN - 1) / TN) * ((Cbi + 1) / 2) * TN * 16;
+}
+void conv1_bf16_pack_host(const float* w /*[Cout][Cin]*/, int Cout, const int* seg_c, int nseg, uint16_t* out) {
+  int Cin = 0, Cbi = 0;
+  for (int s = 0; s < nseg; ++s) { Cin += seg_c[s]; Cbi += (seg_c[s] + 7) / 8; }
+  const int TN = conv_bf16_tn(Cout), Cbp = (Cbi + 1) / 2;
+  memset(out, 0, conv1_bf16_pack_elems(Cout, Cbi) * sizeof(uint16_t));
+  int ci0 = 0, cb0 = 0;
+  for (int s = 0; s < nseg; ++s) {
+    for (int c = 0; c < seg_c[s]; ++c) {
+      const int ci = ci0 + c, cb = cb0 + c / 8, c8 = c % 8;
+      const int pair = cb >> 1, half = cb & 1;
+      for (int co = 0; co < Cout; ++co) {
+        const int nt = co / TN, col = co % TN;
+        const int slot = half ^ ((col >> 3) & 1);
+        out[(((size_t)nt * Cbp + pair) * TN + col) * 16 + slot * 8 + c8] = f32_to_bf16_rne(w[(size_t)co * Cin + ci]);
+      }
+    }
+    ci0 += seg_c[s];
+    cb0 += (seg_c[s] + 7) / 8;
+  }
+}
+
+hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
+  ConvArgsH ah;
+  ConvArgs& a = ah.c;
+  a.x = (const float*)L.x.p; a.x_nstride = 0; a.x_plane = 0;
+  a.w = (const float*)L.w; a.bias = L.bias;
+  a.y = L.y.p; a.y_nstride = L.y.nstride; a.y_plane = L.y.plane(); a.Cob = L.y.Cb;
+  a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
+  a.gate = L.gate ? L.gate->p : nullptr; a.gate_nstride = L.gate ? L.gate->nstride : 0;
+  a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = L.flags;
+  a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
+  ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
+  if ((L.x.Cb & 1) || L.x.H != L.x.W || L.y.H != L.x.H || L.y.Z != L.x.Z || L.y.N != L.x.N || (L.flags & EPI_UP2))
+    return hipErrorInvalidValue;
+  const int TN = conv_bf16_tn(L.Cout);
+  a.ntile = (L.Cout + TN - 1) / TN;
+  if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
+  const long vox = (long)a.N * a.Z * a.S * a.S;
+#define TM_LAUNCH1H(TN_)                                                                         \
+  do {                                                                                          \
+    using G = H1Geo<TN_>;                                                                       \
+    static bool attr_done = false;                                                              \
+    if (!attr_done) {                                                                           \
+      hipError_t e = hipFuncSetAttribute((const void*)conv1_bf16<TN_>,                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_done = true;                                                                         \
+    }                                                                                           \
+    const long grid = ((vox + G::TM - 1) / G::TM) * a.ntile;                                    \
+    hipLaunchKernelGGL((conv1_bf16<TN_>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
+  } while (0)
+  if (TN == 64) TM_LAUNCH1H(64); else TM_LAUNCH1H(128);
+#undef TM_LAUNCH1H
+  return hipGetLastError();
+}
+
 hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   ConvArgsH ah;
   ConvArgs& a = ah.c;
@@ -227,6 +408,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
   a.gate = nullptr; a.gate_nstride = 0;
   a.N = L.x.N; a.S = L.x.H; a.Z = 2; a.Cbi = L.x.Cb; a.flags = 0;
+  a.y_h = nullptr; a.yh_nstride = 0;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
   if (L.x.Cb & 1 || L.x.Z != 2 || L.y.Z != 2 || L.x.H != L.x.W || L.y.H != L.x.H || L.y.N != L.x.N)
     return hipErrorInvalidValue;

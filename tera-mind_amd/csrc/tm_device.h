@@ -50,6 +50,8 @@ struct ConvArgs {
   const float* res; long res_nstride;
   const float* gate; long gate_nstride;
   int N, S, Z, Cbi, ntile, flags;
+  uint16_t* y_h = nullptr;          // optional bf16 CB8 output INSTEAD of y (strides in elements)
+  long yh_nstride = 0;
 };
 
 template <int WM>
@@ -83,6 +85,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         if (a.res) {
           const f32x4 rv = *(const f32x4*)(a.res + (long)on[mt] * a.res_nstride + pl);
           o = rv + o;
+        }
+        if (a.y_h) {
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          bf16x4_t ob;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+          *(bf16x4_t*)(a.y_h + (long)on[mt] * a.yh_nstride + pl) = ob;
+          continue;
         }
         float* yp = a.y + (long)on[mt] * a.y_nstride + pl;
         if (a.flags & EPI_UP2) {

@@ -62,10 +62,17 @@ struct ConvLaunchH {
   const uint16_t* w = nullptr;      // packed by conv_bf16_pack_host
   const float* bias = nullptr;      // [ceil(Cout/64)*64] fp32
   int Cout = 0;
-  TV y;                             // fp32 CB8 output
+  TV y;                             // fp32 CB8 output (geometry is also used for the bf16 output)
   const TV* res = nullptr;
+  const TV* gate = nullptr;         // conv1 only
+  int flags = 0;                    // conv1 only: EPI_GELU
+  uint16_t* y_h = nullptr;          // conv1 only: write bf16 CB8 INSTEAD of y (next Linear's input)
+  long yh_nstride = 0;
 };
 int conv_bf16_tn(int Cout);
+size_t conv1_bf16_pack_elems(int Cout, int Cbi);
+void conv1_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
+hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s);
 size_t conv_bf16_pack_elems(int Cout, int Cbi);
 void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
 hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s);
@@ -100,6 +107,8 @@ struct PrepLaunch {
   uint16_t* out_h = nullptr;        // bf16 output instead of `out` (conv27_bf16 input), nstride in elements
   long out_h_nstride = 0;
   int pad_blocks = 0;               // extra all-zero channel blocks appended to the bf16 output (pair padding)
+  uint16_t* raw_h = nullptr;        // bf16 instead of `raw` (input of the bf16 skip conv); same pad_blocks
+  long raw_h_nstride = 0;
 };
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
 
@@ -151,8 +160,10 @@ hipError_t launch_rna_mid(const float* rna, int B, int gn, int zs, int G, float*
 
 // ---- windowed cross attention core -----------------------------------------------------
 // q, k, v: CB8 token tensors (tokens = voxels (z h w)); n_h x n_h windows over (H, W).
+// o_h != null: write the result as bf16 CB8 (nstride in elements) instead of into `o`.
 hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float* qnorm_w,
-                              const float* knorm_w, TV o, hipStream_t s);
+                              const float* knorm_w, TV o, hipStream_t s, uint16_t* o_h = nullptr,
+                              long o_h_nstride = 0);
 
 // ---- sampler ---------------------------------------------------------------------------
 struct StepCoefs { float c_recip, c_recipm1, pm1, pm2, sigma, sab_prev, s1m_ab_prev; };

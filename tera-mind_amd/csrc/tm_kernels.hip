@@ -539,12 +539,21 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         *(f32x4*)rp = f32x4{r[0], r[1], r[2], r[3]};
         *(f32x4*)(rp + 4) = f32x4{r[4], r[5], r[6], r[7]};
       }
+      if (L.raw_h) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 rb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = (__bf16)r[j];
+        *(bf16x8*)(L.raw_h + (long)n * L.raw_h_nstride + (long)cbv * oplane + oin) = rb;
+      }
     }
     cbo += L.src[k].Cb;
   }
-  if (L.out_h && L.pad_blocks && wv == 0) {
-    for (int pb = 0; pb < L.pad_blocks; ++pb)
-      *(uint4*)(L.out_h + (long)n * L.out_h_nstride + (long)(cbo + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
+  if (L.pad_blocks && wv == 0) {
+    for (int pb = 0; pb < L.pad_blocks; ++pb) {
+      if (L.out_h) *(uint4*)(L.out_h + (long)n * L.out_h_nstride + (long)(cbo + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
+      if (L.raw_h) *(uint4*)(L.raw_h + (long)n * L.raw_h_nstride + (long)(cbo + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
+    }
   }
 }
 
@@ -1050,6 +1059,7 @@ struct WinArgs {
   float* o; long o_ns;
   int C, Z, S;
   long plane;
+  uint16_t* o_h; long o_h_ns;
 };
 
 template <int T>
@@ -1178,9 +1188,18 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
-      float* p = ob + tokoff[ty * TT + i] + (long)(c0 / 8 + tx) * a.plane;
-      *(f32x4*)p = f32x4{oa[i][0], oa[i][1], oa[i][2], oa[i][3]};
-      *(f32x4*)(p + 4) = f32x4{oa[i][4], oa[i][5], oa[i][6], oa[i][7]};
+      const long eo = tokoff[ty * TT + i] + (long)(c0 / 8 + tx) * a.plane;
+      if (a.o_h) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 v8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = (__bf16)oa[i][j];
+        *(bf16x8*)(a.o_h + (long)n * a.o_h_ns + eo) = v8;
+      } else {
+        float* p = ob + eo;
+        *(f32x4*)p = f32x4{oa[i][0], oa[i][1], oa[i][2], oa[i][3]};
+        *(f32x4*)(p + 4) = f32x4{oa[i][4], oa[i][5], oa[i][6], oa[i][7]};
+      }
     }
   }
 }
@@ -1199,8 +1218,9 @@ static hipError_t launch_win(const WinArgs& a, int N, hipStream_t s) {
 }
 
 hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float* qnorm_w, const float* knorm_w,
-                              TV o, hipStream_t s) {
+                              TV o, hipStream_t s, uint16_t* o_h, long o_h_nstride) {
   WinArgs a;
+  a.o_h = o_h; a.o_h_ns = o_h_nstride;
   a.q = q.p; a.k = k.p; a.v = v.p; a.q_ns = q.nstride; a.k_ns = k.nstride; a.v_ns = v.nstride;
   a.qw = qnorm_w; a.kw = knorm_w; a.o = o.p; a.o_ns = o.nstride;
   a.C = q.Cb * 8; a.Z = q.Z; a.S = q.H; a.plane = q.plane();

@@ -48,6 +48,7 @@ struct ResW {
   const float* n1 = nullptr;  // [cbi*8] virtual order
   const float* n2 = nullptr;  // [cout]
   const uint16_t *c1h = nullptr, *c2h = nullptr;   // bf16 packed 3x3x3 weights (TM_DTYPE_BF16)
+  const uint16_t* skiph = nullptr;
   int emb_off = 0;
 };
 struct AttnW {
@@ -55,6 +56,7 @@ struct AttnW {
   int C = 0, G = 0;
   ConvW ada, q, kv, proj, fc1, fc2;
   const float *n1 = nullptr, *n2 = nullptr, *qn = nullptr, *kn = nullptr;
+  const uint16_t *adah = nullptr, *qh = nullptr, *kvh = nullptr, *projh = nullptr, *fc1h = nullptr, *fc2h = nullptr;
 };
 struct DirectW {
   const float* w = nullptr;   // [tap][Cin][Cop]
@@ -381,6 +383,29 @@ static void pack_linear_stack(tm_model* m, Packer& pk, std::vector<Fix>& fx, Con
   for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
   fx.push_back({&cw.bias, boff});
 }
+static void pack_linear_stack_h(tm_model* m, Packer& pk, std::vector<Fix>& fx, std::vector<FixH>& fxh, ConvW& cw,
+                                const uint16_t** wslot, const std::vector<std::string>& pfx, int rows_each,
+                                const std::vector<int>& seg, bool is_conv_key = false) {
+  int Cin = 0, cbi = 0;
+  for (int c : seg) { Cin += c; cbi += (c + 7) / 8; }
+  const int Cout = rows_each * (int)pfx.size();
+  std::vector<float> w((size_t)Cout * Cin), b(Cout);
+  for (size_t i = 0; i < pfx.size(); ++i) {
+    const std::vector<float>& wi = P(m, pfx[i] + ".weight");
+    const std::vector<float>& bi = P(m, pfx[i] + ".bias");
+    memcpy(w.data() + i * (size_t)rows_each * Cin, wi.data(), (size_t)rows_each * Cin * sizeof(float));
+    memcpy(b.data() + i * rows_each, bi.data(), rows_each * sizeof(float));
+  }
+  (void)is_conv_key;
+  cw.Cout = Cout; cw.Cbi = cbi; cw.taps = 1; cw.ntile = (Cout + 63) / 64; cw.w = nullptr;
+  const size_t elems = conv1_bf16_pack_elems(Cout, cbi);
+  size_t off = pk.reserve((elems + 1) / 2);
+  conv1_bf16_pack_host(w.data(), Cout, seg.data(), (int)seg.size(), (uint16_t*)(pk.buf.data() + off));
+  fxh.push_back({wslot, off});
+  size_t boff = pk.reserve((size_t)cw.ntile * 64);
+  for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
+  fx.push_back({&cw.bias, boff});
+}
 static void pack_vec(Packer& pk, std::vector<Fix>& fx, const float** slot, const std::vector<float>& v,
                      const std::vector<int>& seg) {
   int cbi = 0;
@@ -474,12 +499,27 @@ extern "C" int tm_model_finalize(tm_model* m) {
         pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27);
         pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27);
       }
-      if (r.has_skip)
-        pack_conv(m, pk, fx, r.skip, r.pfx + ".skip_connection.weight", r.pfx + ".skip_connection.bias", r.cout, r.seg, 1);
+      if (r.has_skip) {
+        if (bf16) pack_linear_stack_h(m, pk, fx, fxh, r.skip, &r.skiph, {r.pfx + ".skip_connection"}, r.cout, r.seg);
+        else pack_conv(m, pk, fx, r.skip, r.pfx + ".skip_connection.weight", r.pfx + ".skip_connection.bias", r.cout, r.seg, 1);
+      }
       pack_vec(pk, fx, &r.n1, P(m, r.pfx + ".in_layers.0.weight"), r.seg);
       pack_raw(pk, fx, &r.n2, P(m, r.pfx + ".out_layers.0.weight"));
     }
     for (AttnW& a : m->attn) {
+      if (bf16) {
+        pack_linear_stack_h(m, pk, fx, fxh, a.ada, &a.adah, {a.pfx + ".adaLN_modulation.1"}, 7 * a.C, {a.G});
+        pack_linear_stack_h(m, pk, fx, fxh, a.q, &a.qh, {a.pfx + ".attn.q"}, a.C, {a.C});
+        pack_linear_stack_h(m, pk, fx, fxh, a.kv, &a.kvh, {a.pfx + ".attn.k", a.pfx + ".attn.v"}, a.C, {a.C});
+        pack_linear_stack_h(m, pk, fx, fxh, a.proj, &a.projh, {a.pfx + ".attn.proj"}, a.C, {a.C});
+        pack_linear_stack_h(m, pk, fx, fxh, a.fc1, &a.fc1h, {a.pfx + ".mlp.fc1"}, 4 * a.C, {a.C});
+        pack_linear_stack_h(m, pk, fx, fxh, a.fc2, &a.fc2h, {a.pfx + ".mlp.fc2"}, a.C, {4 * a.C});
+        pack_raw(pk, fx, &a.n1, P(m, a.pfx + ".norm1.weight"));
+        pack_raw(pk, fx, &a.n2, P(m, a.pfx + ".norm2.weight"));
+        pack_raw(pk, fx, &a.qn, P(m, a.pfx + ".attn.q_norm.weight"));
+        pack_raw(pk, fx, &a.kn, P(m, a.pfx + ".attn.k_norm.weight"));
+        continue;
+      }
       pack_linear_stack(m, pk, fx, a.ada, {a.pfx + ".adaLN_modulation.1"}, 7 * a.C, a.G);
       pack_linear_stack(m, pk, fx, a.q, {a.pfx + ".attn.q"}, a.C, a.C);
       pack_linear_stack(m, pk, fx, a.kv, {a.pfx + ".attn.k", a.pfx + ".attn.v"}, a.C, a.C);
@@ -645,6 +685,15 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
   }
 }
 
+static void run_conv1_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, const TV* gate,
+                        int flags, TVH* y_h = nullptr) {
+  if (cx.dry) return;
+  ConvLaunchH L;
+  L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
+  if (y_h) { L.y_h = y_h->p; L.yh_nstride = y_h->nstride; }
+  cx.check(launch_conv1_bf16(L, cx.s));
+}
+
 // ResBlock._forward (model/MBAblocks.py:237-299)
 static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, int per_image, int S_out, int mode,
                     TV* out_opt) {
@@ -661,7 +710,11 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   // the residual / skip-conv input is the CONCATENATED (and resampled) x, MBAblocks.py:252-258,297:
   // it equals a stored tensor only for a single plain source
   const bool need_raw = w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage;
-  if (need_raw) raw = cx.tensor(N, cin_pad, Z, S_out);
+  // bf16 mode: a raw that only feeds the skip conv is written as bf16 (no fp32 copy)
+  const bool raw_bf16 = bf16 && w.has_skip;
+  TVH rawh;
+  if (need_raw && raw_bf16) rawh = cx.tensor_h(N, (w.cbi + 1) / 2 * 2, Z, S_out);
+  else if (need_raw) raw = cx.tensor(N, cin_pad, Z, S_out);
   if (!cx.dry) {
     PrepLaunch P;
     P.nsrc = (int)src.size();
@@ -673,7 +726,8 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
     if (bf16) { P.out_h = Ah.p; P.out_h_nstride = Ah.nstride; P.pad_blocks = Ah.Cb - w.cbi; }
     else { P.out = A.p; P.out_nstride = A.nstride; }
-    if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
+    if (need_raw && raw_bf16) { P.raw_h = rawh.p; P.raw_h_nstride = rawh.nstride; }
+    else if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
     cx.check(launch_prep(P, cx.s));
   }
   H1 = cx.tensor(N, w.cout, Z, S_out);
@@ -695,7 +749,7 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   }
   if (bf16) {
     const TV* r = nullptr;
-    if (w.has_skip) { run_conv(cx, raw, w.skip, out, nullptr, nullptr, 0); r = &out; }
+    if (w.has_skip) { run_conv1_h(cx, rawh, w.skiph, w.skip, out, nullptr, nullptr, 0); r = &out; }
     else if (need_raw) r = &raw;
     else r = &src[0].t;
     run_conv_h(cx, A2h, w.c2h, w.c2, out, r, w.cout);
@@ -718,6 +772,44 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
 static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_image, const TV* cond_act = nullptr) {
   const size_t mark = cx.top;
   const int N = x.N, Z = x.Z, S = x.H, C = w.C, cb = C / 8;
+  if (cx.m->cfg.dtype == TM_DTYPE_BF16) {
+    // bf16 operands for every Linear (fp32 accumulate); residual stream x, modulation tensor, q/k/v and the
+    // softmax stay fp32.  Activations that only feed a Linear are produced directly in bf16.
+    const int gbe = ((w.G + 7) / 8 + 1) / 2 * 2;
+    auto prep_h = [&](const float* p, long ns, int Cbs, bool collage, const float* nw, const TV* sc, const TV* sh, int act,
+                      TVH dst, int Creal) {
+      if (cx.dry) return;
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = p; P.src[0].nstride = ns; P.src[0].Cb = Cbs; P.src[0].collage = collage ? 1 : 0;
+      P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = act; P.per_image = per_image;
+      P.norm_w = nw; P.inv_c = 1.0f / (float)Creal;
+      if (sc) { P.mod = MOD_VOXEL; P.mod_scale = sc->p; P.mod_shift = sh->p; P.mod_stride = sc->nstride; }
+      P.out_h = dst.p; P.out_h_nstride = dst.nstride; P.pad_blocks = dst.Cb - Cbs;
+      cx.check(launch_prep(P, cx.s));
+    };
+    TVH cact = cx.tensor_h(N, gbe, Z, S);
+    prep_h(cond.t.p, cond.t.nstride, cond.t.Cb, cond.collage, nullptr, nullptr, nullptr, 1, cact, w.G);
+    TV mod = cx.tensor(N, 7 * C, Z, S);
+    run_conv1_h(cx, cact, w.adah, w.ada, mod, nullptr, nullptr, 0);
+    TV sh_a = mod.blocks(0 * cb, cb), sc_a = mod.blocks(1 * cb, cb), g_a = mod.blocks(2 * cb, cb);
+    TV crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
+    TVH xa = cx.tensor_h(N, cb, Z, S), crsh = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
+    prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
+    prep_h(crs.p, crs.nstride, cb, false, nullptr, nullptr, nullptr, 0, crsh, C);
+    TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, S);
+    run_conv1_h(cx, xa, w.qh, w.q, q, nullptr, nullptr, 0);
+    run_conv1_h(cx, crsh, w.kvh, w.kv, kv, nullptr, nullptr, 0);
+    if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, q, cx.s, oh.p, oh.nstride));
+    run_conv1_h(cx, oh, w.projh, w.proj, x, &x, &g_a, 0);
+    prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
+    TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);
+    TV h1_geom = x; h1_geom.Cb = 4 * cb; h1_geom.C = 4 * C; h1_geom.p = nullptr; h1_geom.nstride = (long)4 * cb * x.plane();
+    run_conv1_h(cx, xa, w.fc1h, w.fc1, h1_geom, nullptr, nullptr, EPI_GELU, &h1);
+    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, &x, &g_m, 0);
+    cx.top = mark;
+    return;
+  }
   // SiLU(cond) (adaLN_modulation[0], MBAblocks.py:464): reuse the activated RNA level when the
   // cond is not re-tiled (encoder / middle), gather + activate for the collage decoder
   TV cact = cond_act ? *cond_act : cx.tensor(N, (w.G + 7) / 8 * 8, Z, S);
