@@ -181,6 +181,10 @@ int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host
 int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
                       int N, int Cin, int Cout, int S, void* stream);
 
+/* bf16 1x1x1 conv / Linear over '(z h w) c' tokens (x and w rounded to bf16, fp32 accumulate). */
+int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
+                     int N, int Cin, int Cout, int Z, int S, int gelu, void* stream);
+
 /* Generic direct Conv3d (stem / head / RNA path), NCDHW in, NCDHW out. */
 int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N,
                       int Cin, int Cout, int Zin, int S, int kz, int ky, int kx, int pz, int py,

@@ -1129,6 +1129,41 @@ extern "C" int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const vo
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv27_bf16 execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
+extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
+                                int Cout, int Z, int S, int gelu, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Cbi = (Cin + 7) / 8, Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64;
+  std::vector<uint16_t> pk(conv1_bf16_pack_elems(Cout, Cbi));
+  conv1_bf16_pack_host((const float*)w_host, Cout, &Cin, 1, pk.data());
+  std::vector<float> bp((size_t)nt64 * 64, 0.f);
+  memcpy(bp.data(), bias_host, Cout * sizeof(float));
+  uint16_t *dw = nullptr, *dx = nullptr;
+  float* db = nullptr;
+  const long vox = (long)Z * S * S;
+  HIP_TRY(hipMalloc((void**)&dw, pk.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMalloc((void**)&db, bp.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&dx, (size_t)N * Cbe * vox * 8 * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, Cin, Z, S, S);
+  PrepLaunch P;
+  P.nsrc = 1;
+  P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+  P.N = N; P.Z = Z; P.S = S;
+  P.out_h = dx; P.out_h_nstride = (long)Cbe * vox * 8; P.pad_blocks = Cbe - Cbi;
+  hipError_t e0 = launch_prep(P, st);
+  ConvLaunchH L;
+  L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = Z; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
+  L.w = dw; L.bias = db; L.Cout = Cout; L.flags = gelu ? EPI_GELU : 0;
+  L.y = view_cb8(y_cb8, N, Cout, Z, S, S);
+  hipError_t e = launch_conv1_bf16(L, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dx);
+  if (e0 != hipSuccess) return fail(TM_ERR_HIP, "launch_prep: %s", hipGetErrorString(e0));
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv1_bf16: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1_bf16 execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}
 extern "C" int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N, int Cin,
                                  int Cout, int Zin, int S, int kz, int ky, int kx, int pz, int py, int px, int silu_in,
                                  int up2_out, void* stream) {

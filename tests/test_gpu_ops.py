@@ -142,3 +142,15 @@ def test_conv27_bf16_random_vs_bf16_rounded_reference():
     full = F.conv3d(x, w, b, padding=1)
     rel = ((got.cpu() - full).norm() / full.norm()).item()
     assert rel < 6e-3, rel                                                          # bf16 operand rounding: ~2^-9 relative
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Z,S", [(2, 229, 1792, 2, 8), (1, 64, 256, 2, 16), (3, 13, 40, 2, 8), (1, 96, 64, 2, 64),
+                                            (5, 512, 2048, 2, 8), (2, 1253, 512, 2, 8), (7, 128, 64, 2, 16)])
+def test_conv1_bf16_exact_integers(N, Cin, Cout, Z, S):
+    """bf16 Linear / 1x1 conv incl. ragged channel-pair stages and ragged voxel tiles."""
+    x = util.rand_int((N, Cin, Z, S, S), -3, 3, 51)
+    w = util.rand_int((Cout, Cin, 1, 1, 1), -2, 2, 52)
+    b = util.rand_int((Cout,), -4, 4, 53)
+    ref = F.conv3d(x, w, b)
+    got, _ = util.conv1_bf16(x.to(DEV), w, b)
+    assert torch.equal(got.cpu(), ref), util.report("conv1 bf16", got, ref)

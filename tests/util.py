@@ -71,6 +71,17 @@ def conv27_bf16(x, w, b):
     return from_cb8(yc, Cout), yc
 
 
+def conv1_bf16(x, w, b, gelu=False):
+    N, Cin, Z, S, _ = x.shape
+    Cout = w.shape[0]
+    xc = to_cb8(x)
+    yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
+    wh, bh = w.contiguous().float(), b.contiguous().float()
+    _lib.check(_lib.lib().tm_op_conv1_bf16(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
+                                           N, Cin, Cout, Z, S, int(gelu), _lib.current_stream_ptr()), "tm_op_conv1_bf16")
+    return from_cb8(yc, Cout), yc
+
+
 def conv_direct(x, w, b, pad, silu_in=False, up2=False):
     N, Cin, Zin, S, _ = x.shape
     Cout, _, kz, ky, kx = w.shape
