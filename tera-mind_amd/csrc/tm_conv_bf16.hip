@@ -192,11 +192,15 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) xf[nxt][mt] = __builtin_bit_cast(bf16x8, buf[xb[mt] + xd]);
       }
+      // keep tap t+1's ds_reads above tap t's MFMAs (hipcc otherwise sinks them to just before their use and
+      // every 8-MFMA group eats a full LDS round trip)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
           acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][ct], xf[cur][mt], acc[ct][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();          // drains this wave's LDS-DMA (vmcnt) and fences the buffer swap
   }
