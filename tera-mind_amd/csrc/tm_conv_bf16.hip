@@ -208,21 +208,29 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
 }
 
 // ---- 1x1x1 conv / Linear on '(z h w) c' tokens, bf16 operands (flat voxel tiles) -----------
-// No tap reuse: staging is 4096*(1/TN + 1/TM) = 40 B/clk/CU at the matrix-pipe rate, so this kernel
-// is L2->LDS bound (~30 % of the bf16 MFMA peak at best), still ~8x the fp32 form.
+// No tap reuse: at the matrix-pipe rate the staging traffic is 4096*(1/TN + 1/TM) = 40 B/clk/CU, i.e. about
+// 100 KB must be in flight per CU to cover an L2/HBM round trip.  Structure: a ring of NB LDS buffers filled
+// by LDS-DMA, NB-1 stages in flight, ONE raw s_barrier per stage and a COUNTED s_waitcnt vmcnt so that the
+// younger stages stay in flight across the barrier (cdna guide, "Pipelining across barriers").  Every
+// LDS-DMA instruction is issued unconditionally -- pieces that do not exist (voxels past the end, channel
+// pairs past Cbp, ring slots past the last stage) read a zero page -- so each wave issues exactly LPS
+// instructions per stage and the vmcnt immediate is a compile-time constant.
 template <int TN>
 struct H1Geo {
   static constexpr int WNW = TN / 64, WMW = 8 / WNW, TM = WMW * 128;
-  static constexpr int KP = (TN == 128) ? 3 : 2;                 // channel-block pairs per stage (LDS: 2 x <= 70 KB)
+  static constexpr int KP = TN / 64;                             // channel-block pairs per stage (1 | 2)
+  static constexpr int NB = 3;                                   // ring depth
   static constexpr int WPIECES = KP * TN * 2, XPIECES = KP * TM * 2;
-  static constexpr int PW = (WPIECES + 511) / 512, PX = XPIECES / 512;
-  static constexpr int BUF16 = WPIECES + XPIECES;
-  static constexpr int LDS_BYTES = 2 * BUF16 * 16;
+  static constexpr int WSLOTS = 512;                             // weight region padded to one instruction per wave
+  static constexpr int PW = 1, PX = XPIECES / 512, LPS = PW + PX;
+  static constexpr int BUF16 = WSLOTS + XPIECES;
+  static constexpr int LDS_BYTES = NB * BUF16 * 16;
 };
 
 template <int TN>
-__global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah) {
+__global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* zero_page) {
   using G = H1Geo<TN>;
+  static_assert(G::WPIECES <= G::WSLOTS && G::XPIECES % 512 == 0, "staging shape");
   const ConvArgs& a = ah.c;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
   const int tid = threadIdx.x;
@@ -235,12 +243,13 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah) {
   const long VPN = (long)a.Z * a.S * a.S, vtot = VPN * a.N;
   const __bf16* xg = (const __bf16*)a.x;
   const __bf16* wg = (const __bf16*)a.w;
+  const __bf16* zp = (const __bf16*)zero_page;
 
   long xoff[G::PX];
   int xkp[G::PX];
 #pragma unroll
   for (int k = 0; k < G::PX; ++k) {
-    const int i = tid + k * 512;                       // piece i -> LDS slot WPIECES + i  ([kp][k-half][voxel])
+    const int i = tid + k * 512;                       // piece i -> LDS slot WSLOTS + i  ([kp][k-half][voxel])
     const int v = i % G::TM;
     const int half = (i / G::TM) & 1;
     xkp[k] = i / (2 * G::TM);
@@ -252,14 +261,15 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah) {
     }
     xoff[k] = off;
   }
-  // packed weights: [n-tile][pair][TN][2][8]
+  // packed weights: [n-tile][pair][TN][2][8]; this lane's piece tid of a stage belongs to pair tid / (TN*2)
   const __bf16* wsrc = wg + (long)nt * ah.Cbp * TN * 16 + (long)tid * 8;
+  const int wkp = tid / (TN * 2);
 
   int xb[4], on[4], ooff[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int v = (wm * 4 + mt) * 32 + i32;
-    xb[mt] = G::WPIECES + h * G::TM + v;               // consecutive lanes, consecutive slots: conflict free
+    xb[mt] = G::WSLOTS + h * G::TM + v;                // consecutive lanes, consecutive slots: conflict free
     const long vg = (long)mtile * G::TM + v;
     if (vg < vtot) {
       const long n = vg / VPN;
@@ -278,32 +288,36 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah) {
       for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
 
   const int NS = (ah.Cbp + G::KP - 1) / G::KP;
-  // Slots a stage does not load: (a) voxels past the end of the tensor -- their MFMA columns are discarded by
-  // the epilogue and a column never feeds another; (b) channel pairs past Cbp in the last stage -- they would
-  // hold the data of two stages ago, so their MFMAs are skipped below.
-  auto issue_stage = [&](int st) {
+  auto issue_stage = [&](int st) {                      // exactly LPS LDS-DMA instructions, whatever st is
     const int p0 = st * G::KP;
-    u32x4* base = lds16 + (st & 1) * G::BUF16;
-#pragma unroll
-    for (int k = 0; k < G::PW; ++k) {
-      const int i0 = k * 512 + wv * 64;                // wave-uniform
-      if (i0 < G::WPIECES && p0 + i0 / (TN * 2) < ah.Cbp) TM_GLDS16(wsrc + (long)p0 * TN * 16 + (long)k * 512 * 8, base + i0);
-    }
+    u32x4* base = lds16 + (st % G::NB) * G::BUF16;
+    // the source address is selected arithmetically and laundered through a VGPR: a `cond ? ptr : zp` that
+    // hipcc turns into two predicated DMA instructions would break the per-stage instruction count
+    const bool wok = st < NS && tid < G::WPIECES && p0 + wkp < ah.Cbp;
+    unsigned long long wa = wok ? (unsigned long long)(wsrc + (long)p0 * TN * 16) : (unsigned long long)zp;
+    asm volatile("" : "+v"(wa));
+    TM_GLDS16((const void*)wa, base + wv * 64);
 #pragma unroll
     for (int k = 0; k < G::PX; ++k) {
       const int pr = p0 + xkp[k];
-      if (xoff[k] >= 0 && pr < ah.Cbp) TM_GLDS16(xg + (long)pr * 2 * ah.x_plane_e + xoff[k], base + G::WPIECES + k * 512 + wv * 64);
+      const bool ok = st < NS && xoff[k] >= 0 && pr < ah.Cbp;
+      unsigned long long xa = ok ? (unsigned long long)(xg + (long)pr * 2 * ah.x_plane_e + xoff[k]) : (unsigned long long)zp;
+      asm volatile("" : "+v"(xa));
+      TM_GLDS16((const void*)xa, base + G::WSLOTS + k * 512 + wv * 64);
     }
   };
 
-  issue_stage(0);
-  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < G::NB - 1; ++st) issue_stage(st);
   for (int st = 0; st < NS; ++st) {
-    if (st + 1 < NS) issue_stage(st + 1);
-    const u32x4* buf = lds16 + (st & 1) * G::BUF16;
+    // stage st has landed once at most (NB-2) younger stages of this wave are still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NB - 2) * G::LPS) : "memory");
+    __builtin_amdgcn_s_barrier();                       // everyone's share landed; buffer (st-1)%NB is free
+    __builtin_amdgcn_sched_barrier(0);
+    issue_stage(st + G::NB - 1);
+    const u32x4* buf = lds16 + (st % G::NB) * G::BUF16;
 #pragma unroll
     for (int kp = 0; kp < G::KP; ++kp) {
-      if (st * G::KP + kp >= ah.Cbp) break;
       bf16x8 wf[2], xf[4];
       wf[0] = __builtin_bit_cast(bf16x8, buf[kp * TN * 2 + wb]);
       wf[1] = __builtin_bit_cast(bf16x8, buf[kp * TN * 2 + 64 + wb]);
@@ -315,8 +329,9 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah) {
         for (int mt = 0; mt < 4; ++mt)
           acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct], xf[mt], acc[ct][mt], 0, 0, 0);
     }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail's dummy DMAs before the LDS is released
   conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 0);
 }
 
@@ -385,7 +400,20 @@ void conv1_bf16_pack_host(const float* w /*[Cout][Cin]*/, int Cout, const int* s
   }
 }
 
+static const void* zero_page(hipError_t* err) {
+  static void* zp = nullptr;                            // 256 B of zeros, lives for the process
+  if (!zp) {
+    hipError_t e = hipMalloc(&zp, 256);
+    if (e == hipSuccess) e = hipMemset(zp, 0, 256);
+    if (e != hipSuccess) { *err = e; zp = nullptr; }
+  }
+  return zp;
+}
+
 hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
+  hipError_t zerr = hipSuccess;
+  const void* zp = zero_page(&zerr);
+  if (!zp) return zerr;
   ConvArgsH ah;
   ConvArgs& a = ah.c;
   a.x = (const float*)L.x.p; a.x_nstride = 0; a.x_plane = 0;
@@ -413,7 +441,7 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
       attr_done = true;                                                                         \
     }                                                                                           \
     const long grid = ((vox + G::TM - 1) / G::TM) * a.ntile;                                    \
-    hipLaunchKernelGGL((conv1_bf16<TN_>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
+    hipLaunchKernelGGL((conv1_bf16<TN_>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah, zp); \
   } while (0)
   if (TN == 64) TM_LAUNCH1H(64); else TM_LAUNCH1H(128);
 #undef TM_LAUNCH1H

@@ -399,7 +399,9 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
 // ==========================================================================================
 struct PrepArgs { PrepLaunch L; };
 
-template <int NSUB>
+// CACHED: the voxel's channel blocks owned by this wave (<= 8) stay in registers between the
+// sum-of-squares pass and the apply pass, so every source byte is read from HBM once.
+template <int NSUB, bool CACHED>
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
   const PrepLaunch& L = pa.L;
   __shared__ float red[4][NSUB][64];
@@ -442,21 +444,41 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
       soff[k][sub] = (long)ns * L.src[k].nstride + ((long)(z * Ss + ys) * Ss + xs) * 8;
     }
   }
+  // this wave owns the virtual (concatenated) channel blocks gb = wv, wv + 4, wv + 8, ...
+  const int cb0 = L.src[0].Cb, cb01 = cb0 + ((L.nsrc > 1) ? L.src[1].Cb : 0);
+  const int cbtot = cb01 + ((L.nsrc > 2) ? L.src[2].Cb : 0);
+  auto src_ptr = [&](int gb, int sub) -> const float* {
+    const int k = (gb >= cb0) + (gb >= cb01);
+    const int cb = gb - (k == 0 ? 0 : (k == 1 ? cb0 : cb01));
+    return L.src[k].p + soff[k][sub] + (long)cb * splane[k];
+  };
+  constexpr int NC = CACHED ? 8 : 1;
+  f32x4 c0[NC], c1[NC];            // CACHED only (NSUB == 1)
+
   float rstd[NSUB];
 #pragma unroll
   for (int sub = 0; sub < NSUB; ++sub) rstd[sub] = 1.f;
-  if (L.norm_w) {
+  if (L.norm_w || CACHED) {
     float ssq[NSUB];
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) ssq[sub] = 0.f;
     if (valid) {
+      if (CACHED) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (k >= L.nsrc) continue;
-        for (int cb = wv; cb < L.src[k].Cb; cb += 4) {
+        for (int i = 0; i < NC; ++i) {
+          const int gb = wv + 4 * i;
+          if (gb < cbtot) {
+            const float* p = src_ptr(gb, 0);
+            c0[i] = *(const f32x4*)p; c1[i] = *(const f32x4*)(p + 4);
+            ssq[0] += c0[i][0] * c0[i][0] + c0[i][1] * c0[i][1] + c0[i][2] * c0[i][2] + c0[i][3] * c0[i][3] +
+                      c1[i][0] * c1[i][0] + c1[i][1] * c1[i][1] + c1[i][2] * c1[i][2] + c1[i][3] * c1[i][3];
+          }
+        }
+      } else {
+        for (int gb = wv; gb < cbtot; gb += 4) {
 #pragma unroll
           for (int sub = 0; sub < NSUB; ++sub) {
-            const float* p = L.src[k].p + soff[k][sub] + (long)cb * splane[k];
+            const float* p = src_ptr(gb, sub);
             const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
             ssq[sub] += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] +
                         a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
@@ -464,95 +486,98 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         }
       }
     }
+    if (L.norm_w) {
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) red[wv][sub][lane] = ssq[sub];
-    __syncthreads();
+      for (int sub = 0; sub < NSUB; ++sub) red[wv][sub][lane] = ssq[sub];
+      __syncthreads();
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
-      const float t = red[0][sub][lane] + red[1][sub][lane] + red[2][sub][lane] + red[3][sub][lane];
-      rstd[sub] = 1.0f / sqrtf(t * L.inv_c + TM_EPS);
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const float t = red[0][sub][lane] + red[1][sub][lane] + red[2][sub][lane] + red[3][sub][lane];
+        rstd[sub] = 1.0f / sqrtf(t * L.inv_c + TM_EPS);
+      }
     }
   }
   if (!valid) return;
   const long oplane = vpn * 8;
   const long oin = ((long)(z * S + y) * S + x) * 8;
   const int img = n / L.per_image;
-  int cbo = 0;
+  auto emit = [&](int gb, int i) {
+    float wn[8], sc[8], sh[8];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (k >= L.nsrc) continue;
-    for (int cb = wv; cb < L.src[k].Cb; cb += 4) {
-      const int cbv = cbo + cb;
-      float wn[8], sc[8], sh[8];
+    for (int j = 0; j < 8; ++j) { wn[j] = 1.f; sc[j] = 0.f; sh[j] = 0.f; }
+    if (L.norm_w) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { wn[j] = 1.f; sc[j] = 0.f; sh[j] = 0.f; }
-      if (L.norm_w) {
+      for (int j = 0; j < 8; ++j) wn[j] = L.norm_w[gb * 8 + j];
+    }
+    if (L.mod == MOD_IMAGE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wn[j] = L.norm_w[cbv * 8 + j];
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = L.mod_scale[(long)img * L.mod_stride + gb * 8 + j];
+        sh[j] = L.mod_shift[(long)img * L.mod_stride + gb * 8 + j];
       }
-      if (L.mod == MOD_IMAGE) {
+    } else if (L.mod == MOD_VOXEL) {
+      const long mo = (long)n * L.mod_stride + (long)gb * oplane + oin;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sc[j] = L.mod_scale[(long)img * L.mod_stride + cbv * 8 + j];
-          sh[j] = L.mod_shift[(long)img * L.mod_stride + cbv * 8 + j];
-        }
-      } else if (L.mod == MOD_VOXEL) {
-        const long mo = (long)n * L.mod_stride + (long)cbv * oplane + oin;
+      for (int j = 0; j < 8; ++j) { sc[j] = L.mod_scale[mo + j]; sh[j] = L.mod_shift[mo + j]; }
+    }
+    float o[8], r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = L.mod_scale[mo + j]; sh[j] = L.mod_shift[mo + j]; }
-      }
-      float o[8], r[8];
+    for (int j = 0; j < 8; ++j) { o[j] = 0.f; r[j] = 0.f; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { o[j] = 0.f; r[j] = 0.f; }
+    for (int sub = 0; sub < NSUB; ++sub) {
+      f32x4 a0, a1;
+      if (CACHED) { a0 = c0[i]; a1 = c1[i]; }
+      else { const float* p = src_ptr(gb, sub); a0 = *(const f32x4*)p; a1 = *(const f32x4*)(p + 4); }
+      const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        const float* p = L.src[k].p + soff[k][sub] + (long)cb * splane[k];
-        const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
-        const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = xv[j];
-          r[j] += v;
-          if (L.norm_w) v = wn[j] * (v * rstd[sub]);
-          if (L.mod != MOD_NONE) v = v * (1.0f + sc[j]) + sh[j];
-          if (L.act) v = silu_f(v);
-          o[j] += v;
-        }
-      }
-      if (NSUB == 4) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] *= 0.25f; r[j] *= 0.25f; }
-      }
-      if (L.out_h) {
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        bf16x8 ob;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ob[j] = (__bf16)o[j];
-        *(bf16x8*)(L.out_h + (long)n * L.out_h_nstride + (long)cbv * oplane + oin) = ob;
-      } else {
-        float* op = L.out + (long)n * L.out_nstride + (long)cbv * oplane + oin;
-        *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
-        *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
-      }
-      if (L.raw) {
-        float* rp = L.raw + (long)n * L.raw_nstride + (long)cbv * oplane + oin;
-        *(f32x4*)rp = f32x4{r[0], r[1], r[2], r[3]};
-        *(f32x4*)(rp + 4) = f32x4{r[4], r[5], r[6], r[7]};
-      }
-      if (L.raw_h) {
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        bf16x8 rb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rb[j] = (__bf16)r[j];
-        *(bf16x8*)(L.raw_h + (long)n * L.raw_h_nstride + (long)cbv * oplane + oin) = rb;
+      for (int j = 0; j < 8; ++j) {
+        float v = xv[j];
+        r[j] += v;
+        if (L.norm_w) v = wn[j] * (v * rstd[sub]);
+        if (L.mod != MOD_NONE) v = v * (1.0f + sc[j]) + sh[j];
+        if (L.act) v = silu_f(v);
+        o[j] += v;
       }
     }
-    cbo += L.src[k].Cb;
+    if (NSUB == 4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[j] *= 0.25f; r[j] *= 0.25f; }
+    }
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const long eo = (long)gb * oplane + oin;
+    if (L.out_h) {
+      bf16x8 ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ob[j] = (__bf16)o[j];
+      *(bf16x8*)(L.out_h + (long)n * L.out_h_nstride + eo) = ob;
+    } else if (L.out) {
+      float* op = L.out + (long)n * L.out_nstride + eo;
+      *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
+      *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+    if (L.raw) {
+      float* rp = L.raw + (long)n * L.raw_nstride + eo;
+      *(f32x4*)rp = f32x4{r[0], r[1], r[2], r[3]};
+      *(f32x4*)(rp + 4) = f32x4{r[4], r[5], r[6], r[7]};
+    }
+    if (L.raw_h) {
+      bf16x8 rb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rb[j] = (__bf16)r[j];
+      *(bf16x8*)(L.raw_h + (long)n * L.raw_h_nstride + eo) = rb;
+    }
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (wv + 4 * i < cbtot) emit(wv + 4 * i, i);
+  } else {
+    for (int gb = wv; gb < cbtot; gb += 4) emit(gb, 0);
   }
   if (L.pad_blocks && wv == 0) {
     for (int pb = 0; pb < L.pad_blocks; ++pb) {
-      if (L.out_h) *(uint4*)(L.out_h + (long)n * L.out_h_nstride + (long)(cbo + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
-      if (L.raw_h) *(uint4*)(L.raw_h + (long)n * L.raw_h_nstride + (long)(cbo + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
+      if (L.out_h) *(uint4*)(L.out_h + (long)n * L.out_h_nstride + (long)(cbtot + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
+      if (L.raw_h) *(uint4*)(L.raw_h + (long)n * L.raw_h_nstride + (long)(cbtot + pb) * oplane + oin) = uint4{0u, 0u, 0u, 0u};
     }
   }
 }
@@ -561,8 +586,11 @@ hipError_t launch_prep(const PrepLaunch& L, hipStream_t s) {
   PrepArgs pa; pa.L = L;
   const long vox = (long)L.N * L.Z * L.S * L.S;
   const unsigned grid = (unsigned)((vox + 63) / 64);
-  if (L.resample == RS_DOWN2) hipLaunchKernelGGL(prep_kernel<4>, dim3(grid), dim3(256), 0, s, pa);
-  else hipLaunchKernelGGL(prep_kernel<1>, dim3(grid), dim3(256), 0, s, pa);
+  int cbtot = 0;
+  for (int k = 0; k < L.nsrc; ++k) cbtot += L.src[k].Cb;
+  if (L.resample == RS_DOWN2) hipLaunchKernelGGL((prep_kernel<4, false>), dim3(grid), dim3(256), 0, s, pa);
+  else if (cbtot <= 32) hipLaunchKernelGGL((prep_kernel<1, true>), dim3(grid), dim3(256), 0, s, pa);
+  else hipLaunchKernelGGL((prep_kernel<1, false>), dim3(grid), dim3(256), 0, s, pa);
   return hipGetLastError();
 }
 
