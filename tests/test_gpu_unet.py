@@ -152,3 +152,59 @@ def test_unet_forward_bf16_convs():
         rel = ((out - ref).norm() / ref.norm()).item()
         print(util.report(f"bf16 b{b} P{P}", out, ref), "rel_l2=%.3e" % rel)
         assert rel < 6e-3 and (out - ref).abs().max() < 0.03, util.report("bf16", out, ref)
+
+
+@pytest.mark.parametrize("stain", ["DAPI", "PolyT"])
+def test_unet_single_stain_config(stain):
+    """stain != 'all': one stain x 2 z-slices = 2 image channels (config surface of train.py:33-35);
+    the oracle was validated against the reference for these configs (1.97e-6)."""
+    cfg = PathConfig(stain=stain)
+    oc = tc.oracle_config_from(cfg)
+    sd = util.state_dict(cfg)
+    m = BeatGANsUNetModel(cfg, DEV).load_state_dict(sd)
+    b, P = 2, 1
+    ne = b * (P + 1) ** 2
+    x = synth.normal("x", (ne, cfg.in_channels, 64, 64), 7)
+    rna = synth.gene_counts("rna", (ne, 4, 4, 2000), 7)
+    t = torch.tensor([11, 950])
+    with torch.inference_mode():
+        ref, ref2 = tc.unet_forward(sd, oc, x, t, rna, 2, 2, want_pred2=True)
+    out = m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(b, cfg.in_channels, 64, 64), patch_size=64, want_pred2=True)
+    assert out.pred.shape == (b, 2, 64, 64)
+    assert torch.allclose(out.pred.cpu(), ref, atol=ATOL, rtol=0), util.report("pred", out.pred, ref)
+    assert torch.allclose(out.pred2.cpu(), ref2, atol=ATOL, rtol=0), util.report("pred2", out.pred2, ref2)
+
+
+def test_unet_batch_of_images_with_interior_grid_and_distinct_timesteps():
+    """b = 2 images of 2x3 interior patches (non-square grid), a different t per image: exercises the
+    per-image emb modulation index, the collage index map with p1 != p2 and ragged tile counts."""
+    cfg = PathConfig()
+    oc = tc.oracle_config_from(cfg)
+    sd = util.state_dict(cfg)
+    b, p1, p2 = 2, 3, 4
+    ne = b * p1 * p2
+    x = synth.normal("x23", (ne, 4, 64, 64), 1)
+    rna = synth.gene_counts("rna23", (ne, 4, 4, 2000), 1)
+    t = torch.tensor([3, 871])
+    with torch.inference_mode():
+        ref, _ = tc.unet_forward(sd, oc, x, t, rna, p1, p2)
+    out = hip_model()(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(b, 4, 64 * (p1 - 1), 64 * (p2 - 1)), patch_size=64)
+    assert out.pred.shape == (b * 2 * 3, 4, 64, 64)
+    assert torch.allclose(out.pred.cpu(), ref, atol=ATOL, rtol=0), util.report("pred", out.pred, ref)
+
+
+def test_forward_argument_validation():
+    m = hip_model()
+    x, t, rna = make_inputs(1, 1)
+    with pytest.raises(ValueError):
+        m(x=x[:3].to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64), patch_size=64)
+    with pytest.raises(ValueError):
+        m(x=x.to(DEV), t=t.to(DEV), rna=rna[:, :3].to(DEV), imgs=torch.zeros(1, 4, 64, 64), patch_size=64)
+    with pytest.raises(ValueError):
+        m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64), patch_size=32)
+    with pytest.raises(NotImplementedError):
+        m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64), patch_size=64, do_train=True)
+    with pytest.raises(RuntimeError):
+        BeatGANsUNetModel(PathConfig(), DEV)(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64))
+    with pytest.raises(RuntimeError):
+        BeatGANsUNetModel(PathConfig(), DEV).load_state_dict({"bogus.key": torch.zeros(1)})

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Timed subset of the tile sweep (BASELINE configs 3/4) through the real driver
+(teramind_amd.brain.TileSweep + SpacedDiffusionBeatGans + BeatGANsUNetModel), one GPU:
+`--rows x --cols` tiles of 256x256x100, 25 z-chunks each, `--steps` DDIM steps, state resident in HBM.
+Reports seconds per tile-step and the extrapolated wall-clock of the 32x32-tile ROI (and of the
+286x414 whole brain) for T steps on 1 and 8 GPUs (row-sharded: tiles are independent within a step,
+the per-step exchange is a 32-px strip per neighbour).  Extrapolation, not a measurement of those sizes."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1)
+    ap.add_argument("--cols", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--T", type=int, default=15)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--init", choices=["reference", "device"], default="device")
+    args = ap.parse_args()
+    import torch
+    import teramind_amd  # noqa: F401
+    from teramind_amd.brain import TileSweep, synthetic_gene_provider
+    from teramind_amd.config import PathConfig
+    from teramind_amd.diffusion import SpacedDiffusionBeatGans
+    from teramind_amd.unet import BeatGANsUNetModel
+    from teramind_amd.weights import hashed_state_dict
+
+    dev = "cuda:0"
+    cfg = PathConfig(compute_dtype=args.dtype)
+    model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
+    host_genes = synthetic_gene_provider(cfg, total_slc=50)
+    resident = {}
+
+    def genes(row, col):                       # gene tiles resident in HBM (built once, outside the timing)
+        if (row, col) not in resident:
+            resident[(row, col)] = host_genes(row, col).to(dev)
+        return resident[(row, col)]
+
+    sw = TileSweep(cfg, SpacedDiffusionBeatGans(args.T, "ddim"), model, genes, hst=256, wst=256, hnm=args.rows,
+                   wnm=args.cols, total_epochs=args.T, total_slc=50, device=dev, batch_tiles=1, init=args.init)
+    for r in range(args.rows):
+        for c in range(args.cols):
+            genes(1 + r, 1 + c)
+    sw.step()                                   # warm-up (workspace allocation, first-touch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sw.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tiles = args.rows * args.cols
+    per = dt / (args.steps * tiles)
+    st = sw.local_state()
+    out = {"what": "TileSweep timed subset", "dtype": args.dtype, "tiles": tiles, "steps_timed": args.steps,
+           "z_chunks_per_tile": 25, "interior_patch_steps_per_tile_step": 400,
+           "s_per_tile_step": round(per, 4), "interior_patch_steps_per_s": round(400 / per, 1),
+           "state_finite": bool(torch.isfinite(st).all()), "state_absmax": float(st.abs().max()),
+           "extrapolated": {
+               f"roi_32x32_T{args.T}_1gpu_min": round(1024 * args.T * per / 60, 1),
+               f"roi_32x32_T{args.T}_8gpu_min": round(1024 * args.T * per / 8 / 60, 1),
+               "roi_32x32_T50_8gpu_min": round(1024 * 50 * per / 8 / 60, 1),
+               f"whole_brain_286x414_T{args.T}_8gpu_h": round(36 * 414 * args.T * per / 3600, 1)}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
