@@ -901,7 +901,7 @@ struct GeneArgs {
 #define GENE_QP 65      // padded row of the normalised-q image: conflict-free key reads
 
 #define GENE_WAVES 4
-#define GENE_SPLIT 2      // workgroups per patch: rows of passes B/C are interleaved over them
+// gridDim.y workgroups per patch share the rows of passes B/C (2 when the batch alone would leave CUs idle)
 // token (n, gene g, feature d = (z h w)) inside the CB8 tensor [B][ceil(G/8)][zs][gn][gn][8]
 __device__ __forceinline__ long gene_tok_idx(int n, int g, int d, int Gb) {
   return (((long)n * Gb + (g >> 3)) * GENE_D + d) * 8 + (g & 7);
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(64 * GENE_WAVES) void gene_attn_kernel(GeneArgs a) 
       for (int k = 0; k < GENE_D; ++k) { wvv[k] = a.w.wv_t[k * GENE_D + lane]; wpp[k] = a.w.wp_t[k * GENE_D + lane]; }
     }
     float* pr = prow + wv * Gp;
-    for (int g = wv + GENE_WAVES * blockIdx.y; g < G; g += GENE_WAVES * GENE_SPLIT) {
+    for (int g = wv + GENE_WAVES * blockIdx.y; g < G; g += GENE_WAVES * gridDim.y) {
       float lg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
       for (int d = 0; d < GENE_D; ++d) {
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(64 * GENE_WAVES) void gene_attn_kernel(GeneArgs a) 
   float* w2 = sm + 64 * 256;       // [256][64]
   for (int i = tid; i < 64 * 256; i += NT) { w1[i] = a.w.w1_t[i]; w2[i] = a.w.w2_t[i]; }
   __syncthreads();
-  for (int g = wv + GENE_WAVES * blockIdx.y; g < G; g += GENE_WAVES * GENE_SPLIT) {
+  for (int g = wv + GENE_WAVES * blockIdx.y; g < G; g += GENE_WAVES * gridDim.y) {
     const float hv = a.scratch[gene_tok_idx(n, g, lane, Gb)];
     float y1[4];
 #pragma unroll
@@ -1052,7 +1052,7 @@ hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, cons
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gene_attn_kernel, dim3(B, GENE_SPLIT), dim3(64 * GENE_WAVES), lds, s, a);
+  hipLaunchKernelGGL(gene_attn_kernel, dim3(B, B >= 256 ? 1 : 2), dim3(64 * GENE_WAVES), lds, s, a);
   return hipGetLastError();
 }
 
