@@ -30,7 +30,74 @@ struct ConvArgsH {
   ConvArgs c;                 // x / w are reinterpreted: x = bf16 CB8 (elements), w = bf16 packed
   long x_nstride_e, x_plane_e;   // in bf16 elements
   int Cbp;                    // channel-block pairs
+  // fused ResBlock mid-section (only when the workgroup holds every cout of its voxels, n-tile count 1):
+  // out_layers[0] RMSNorm(C) * w -> x(1+scale)+shift -> SiLU (MBAblocks.py:196-203,356-367) written as the bf16
+  // input of the second conv; the fp32 conv output itself is not stored.
+  int fuse;
+  const float* norm_w; const float* mod_scale; const float* mod_shift;
+  long mod_stride; int per_image; float inv_c;
+  uint16_t* a2; long a2_nstride;
 };
+
+template <int WNW>
+__device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 (&acc)[2][4], int wn, int wm, int i32, int h,
+                                                    const int (&on)[4], const int (&ooff)[4], float* red) {
+  const ConvArgs& a = ah.c;
+  float ss[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) ss[mt] = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(a.bias + (long)(wn * 8 + ct * 4 + g) * 8 + 4 * h);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[ct][mt][4 * g + j] + bv[j];
+          acc[ct][mt][4 * g + j] = v;
+          ss[mt] += v * v;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) ss[mt] += __shfl_xor(ss[mt], 32, 64);       // the voxel's other 4-cout halves
+  if (WNW == 2) {                                                              // ... and its other 64 couts
+    if (h == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) red[((wm * 4 + mt) * 2 + wn) * 32 + i32] = ss[mt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) ss[mt] += red[((wm * 4 + mt) * 2 + (wn ^ 1)) * 32 + i32];
+  }
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (ooff[mt] < 0) continue;
+    const float rstd = 1.0f / sqrtf(ss[mt] * ah.inv_c + TM_EPS);
+    const long mo = (long)(on[mt] / ah.per_image) * ah.mod_stride;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cob = wn * 8 + ct * 4 + g;
+        const int c0 = cob * 8 + 4 * h;
+        const f32x4 w4 = *(const f32x4*)(ah.norm_w + c0);
+        const f32x4 sc = *(const f32x4*)(ah.mod_scale + mo + c0), sh = *(const f32x4*)(ah.mod_shift + mo + c0);
+        bf16x4_t ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = w4[j] * (acc[ct][mt][4 * g + j] * rstd);
+          v = v * (1.0f + sc[j]) + sh[j];
+          ob[j] = (__bf16)silu_f(v);
+        }
+        *(bf16x4_t*)(ah.a2 + (long)on[mt] * ah.a2_nstride + (long)cob * a.y_plane + ooff[mt] + 4 * h) = ob;
+        __builtin_amdgcn_sched_barrier(0);          // keep the per-(cout block) loads from being hoisted en masse
+      }
+  }
+}
 
 // Activation image in LDS: two arrays (k-half 0 / 1) of 16-byte slots [patch][halo row][pitch]; a lane reads
 // slot(vox) of array h.  ds_read_b128 is served in the 16-lane groups G1 = {0-3,12-15,20-27} and
@@ -74,7 +141,7 @@ __device__ __forceinline__ void col_to_vox(int T, int i32, int& ps, int& r, int&
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int TN, int TW>
+template <int TN, int TW, bool FUSE>
 __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   using G = HGeo<TN, TW>;
   const ConvArgs& a = ah.c;
@@ -204,7 +271,8 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
     }
     __syncthreads();          // drains this wave's LDS-DMA (vmcnt) and fences the buffer swap
   }
-  conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 2 * S);
+  if (FUSE) fused_norm_epilogue<G::WNW>(ah, acc, wn, wm, i32, h, on, ooff, (float*)lds16);
+  else conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 2 * S);
 }
 
 // ---- 1x1x1 conv / Linear on '(z h w) c' tokens, bf16 operands (flat voxel tiles) -----------
@@ -423,6 +491,7 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.gate = L.gate ? L.gate->p : nullptr; a.gate_nstride = L.gate ? L.gate->nstride : 0;
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = L.flags;
   a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
+  ah.fuse = 0;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
   if ((L.x.Cb & 1) || L.x.H != L.x.W || L.y.H != L.x.H || L.y.Z != L.x.Z || L.y.N != L.x.N || (L.flags & EPI_UP2))
     return hipErrorInvalidValue;
@@ -458,19 +527,25 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.gate = nullptr; a.gate_nstride = 0;
   a.N = L.x.N; a.S = L.x.H; a.Z = 2; a.Cbi = L.x.Cb; a.flags = 0;
   a.y_h = nullptr; a.yh_nstride = 0;
+  ah.fuse = L.fuse_norm; ah.norm_w = L.norm_w; ah.mod_scale = L.mod_scale; ah.mod_shift = L.mod_shift;
+  ah.mod_stride = L.mod_stride; ah.per_image = L.per_image; ah.inv_c = 1.0f / (float)L.Cout;
+  ah.a2 = L.a2.p; ah.a2_nstride = L.a2.nstride;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
   if (L.x.Cb & 1 || L.x.Z != 2 || L.y.Z != 2 || L.x.H != L.x.W || L.y.H != L.x.H || L.y.N != L.x.N)
     return hipErrorInvalidValue;
   const int S = a.S, TN = conv_bf16_tn(L.Cout);
   a.ntile = (L.Cout + TN - 1) / TN;
   if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
+  if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
   do {                                                                                          \
     using G = HGeo<TN_, TW_>;                                                                   \
     static bool attr_done = false;                                                              \
     if (!attr_done) {                                                                           \
-      hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_>,                    \
+      hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, false>,             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, true>,    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
       attr_done = true;                                                                         \
@@ -478,7 +553,8 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
     const long grid = pgs * 2 * tiles * a.ntile;                                                \
-    hipLaunchKernelGGL((conv27_bf16<TN_, TW_>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
+    if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<TN_, TW_, true>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
+    else hipLaunchKernelGGL((conv27_bf16<TN_, TW_, false>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
   } while (0)
   if (TN == 64) {
     if (S >= 32) TM_LAUNCHH(64, 32); else if (S == 16) TM_LAUNCHH(64, 16); else TM_LAUNCHH(64, 8);

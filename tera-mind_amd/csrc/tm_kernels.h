@@ -68,6 +68,13 @@ struct ConvLaunchH {
   int flags = 0;                    // conv1 only: EPI_GELU
   uint16_t* y_h = nullptr;          // conv1 only: write bf16 CB8 INSTEAD of y (next Linear's input)
   long yh_nstride = 0;
+  // conv27 only, Cout in {64, 128}: fuse RMSNorm(C)*w -> x(1+scale)+shift -> SiLU into the epilogue and write
+  // the bf16 tensor `a2` (the next conv's input) instead of y
+  int fuse_norm = 0;
+  const float *norm_w = nullptr, *mod_scale = nullptr, *mod_shift = nullptr;
+  long mod_stride = 0;
+  int per_image = 1;
+  TVH a2;
 };
 int conv_bf16_tn(int Cout);
 size_t conv1_bf16_pack_elems(int Cout, int Cbi);

@@ -661,11 +661,16 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
   }
 }
 
-static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, int cin_real) {
+static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, int cin_real,
+                       const TVH* fuse_a2 = nullptr, const ResW* rw = nullptr, int per_image = 1) {
   if (cx.dry) return;
   ConvLaunchH L;
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res;
   tm_model* m = cx.m;
+  if (fuse_a2) {
+    L.fuse_norm = 1; L.a2 = *fuse_a2; L.norm_w = rw->n2; L.per_image = per_image;
+    L.mod_scale = cx.ss + rw->emb_off; L.mod_shift = cx.ss + rw->emb_off + rw->cout; L.mod_stride = m->emb_tot;
+  }
   const bool prof = m->prof_on;
   if (prof) {
     if (m->prof_used == m->prof_ev.size()) {
@@ -730,12 +735,21 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     else if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
     cx.check(launch_prep(P, cx.s));
   }
-  H1 = cx.tensor(N, w.cout, Z, S_out);
-  if (bf16) run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin);
-  else run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
+  // bf16, Cout in {64, 128}: one workgroup holds every cout of its voxels, so out_layers' norm -> modulate -> SiLU
+  // runs in the first conv's epilogue and writes the second conv's bf16 input directly
+  const bool fuse_mid = bf16 && (w.cout == 64 || w.cout == 128);
   if (bf16) A2h = cx.tensor_h(N, (w.cout / 8 + 1) / 2 * 2, Z, S_out);
   else A2 = cx.tensor(N, w.cout, Z, S_out);
-  if (!cx.dry) {
+  if (fuse_mid) {
+    TV geom; geom.N = N; geom.C = w.cout; geom.Cb = w.cout / 8; geom.Z = Z; geom.H = S_out; geom.W = S_out;
+    geom.nstride = (long)geom.Cb * geom.plane();
+    run_conv_h(cx, Ah, w.c1h, w.c1, geom, nullptr, w.cin, &A2h, &w, per_image);
+  } else {
+    H1 = cx.tensor(N, w.cout, Z, S_out);
+    if (bf16) run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin);
+    else run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
+  }
+  if (!cx.dry && !fuse_mid) {
     PrepLaunch P;
     P.nsrc = 1;
     P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
