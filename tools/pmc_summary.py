@@ -38,12 +38,12 @@ def main(fetch_csv, write_csv, sq_csv=None, out_json=None):
     for r in rows:
         print(f"{r['kernel'][:28]:28s} {r['launches']:8d} {r['hbm_read_bytes_per_launch'] / 1e6:13.2f} "
               f"{r['hbm_write_bytes_per_launch'] / 1e6:13.2f} {r.get('mfma_busy_over_sq_busy', float('nan')):18.3f}")
-    conv = [r for r in rows if r["kernel"].startswith("conv27_mfma")]
+    conv = [r for r in rows if r["kernel"].startswith("conv3d_mfma<2,") or r["kernel"].startswith("conv27_mfma")]
     n = sum(r["launches"] for r in conv)
     tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in conv)
-    summary = {"kernel": "conv27_mfma (all instantiations)", "launches": n, "hbm_bytes_per_launch": tot / max(1, n),
+    summary = {"kernel": "conv3d_mfma<2,*,*> (3x3x3 z-skip conv, all tile instantiations)", "launches": n, "hbm_bytes_per_launch": tot / max(1, n),
                "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes", "per_kernel": rows}
-    print(f"conv27_mfma: {n} launches, {tot / max(1, n) / 1e6:.1f} MB HBM traffic per launch")
+    print(f"conv3d_mfma<2,*,*>: {n} launches, {tot / max(1, n) / 1e6:.1f} MB HBM traffic per launch")
     if out_json:
         json.dump(summary, open(out_json, "w"), indent=1)
 
