@@ -92,8 +92,10 @@ def integer_paths(ns):
 def tile_driver_paths(ns):
     """a23 / a24: run the reference's own Tester._run_batch and MBADataset_tst._pad_im on stubs."""
     import importlib
-    sys.modules.setdefault("PIL", types.ModuleType("PIL"))
-    if not hasattr(sys.modules["PIL"], "Image"):
+    try:
+        import PIL.Image  # noqa: F401
+    except Exception:
+        sys.modules["PIL"] = types.ModuleType("PIL")
         sys.modules["PIL"].Image = types.SimpleNamespace()
         sys.modules["PIL.Image"] = sys.modules["PIL"].Image
     out = {}
@@ -253,6 +255,30 @@ def main():
           "attn_glst": attn[:, :, glst][:, :, :, glst].numpy(), "mid": mid.numpy()}
     np.savez_compressed(os.path.join(OUT, "attn_maps.npz"), **g6)
     print("G6 attention maps written")
+    # ---------------- G7 attention driver read-out: the reference's own test_attn.Tester._run_batch ----------------
+    import importlib
+    for name in ("pyvips", "seaborn"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ta = importlib.import_module("test_attn")
+    saved = {}
+    ta.zarr.save_array = lambda p, a: saved.__setitem__(str(p), a)
+    tt = ta.Tester.__new__(ta.Tester)
+    tt.gpu_id = "cpu"
+    tt.conf = types.SimpleNamespace(patch_size=64, gn_sz=4, fp16=True)
+    tt.z_size, tt.tot_slc, tt.tot_rna, tt.n_stn, tt.glst = 4, 50, 500, 2, [75, 191]
+    tt.model = mv
+    tile = synth.gene_counts("attn/tile", (1, 20, 20, 26000), 0, density=0.05)
+    dat, crd, ssz = synth.dense_to_coo(tile)
+    from pathlib import Path
+    with torch.inference_mode():
+        tt._run_batch((torch.zeros(1, 320, 320, 100), torch.tensor([[256, 512, 512, 768]]), dat, crd, ssz, torch.tensor([0])), 0, Path("o"))
+    arr = list(saved.values())[0]
+    np.savez_compressed(os.path.join(OUT, "attn_readout.npz"), out=arr)
+    print("G7 attention read-out written", arr.shape, arr.dtype)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")
 

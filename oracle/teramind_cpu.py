@@ -529,3 +529,37 @@ def unchunk_state(out: Tensor, b: int, n_stain: int) -> Tensor:
     nzb, sz, h, w = out.shape
     nz, zc = nzb // b, sz // n_stain
     return out.reshape(nz, b, n_stain, zc, h, w).permute(1, 2, 0, 3, 4, 5).reshape(b, n_stain * nz * zc, h, w)
+
+
+# ------------------------------------------------------------------------------------------
+# attention driver read-out (K18)
+# ------------------------------------------------------------------------------------------
+def pathway_readout(attn: Tensor, rna_mid: Tensor, glst: Sequence[int]) -> Tensor:
+    """test_attn.py:404-423: products of the slice-pair / ensemble maps of the pathway genes with their counts."""
+    g = list(glst)
+    B = attn.shape[1]
+    pick = lambda a: a[:, :, g][..., g]
+    rna = rna_mid[:, g]
+    r0, r1 = rna[:, :, 0].reshape(B, len(g), -1), rna[:, :, 1].reshape(B, len(g), -1)
+    a0 = pick(attn[:2]).permute(1, 0, 2, 3).reshape(B, -1, len(g))
+    a1 = pick(attn[1:3]).permute(1, 0, 2, 3).reshape(B, -1, len(g))
+    out = torch.cat([a0 @ r0, a1 @ r1], -1)
+    r2 = rna.reshape(B, len(g), -1)
+    return torch.cat([out, pick(attn[3:4])[0] @ r2, r2], 1)
+
+
+def attn_tile_readout(W, cfg: OracleConfig, rna_tile: Tensor, glst: Sequence[int]) -> Tensor:
+    """test_attn.Tester._run_batch end to end for dense gene tiles [b, 20, 20, 26000] -> fp16 [b,50,8,16,16]."""
+    b, gn = rna_tile.shape[0], cfg.gn_sz
+    r = zchunk_rna(rna_tile, cfg.rna_slc)
+    p1, p2 = r.shape[1] // gn, r.shape[2] // gn
+    n = r.shape[0]
+    r = r.reshape(n, p1, gn, p2, gn, -1).permute(0, 1, 3, 2, 4, 5).reshape(n * p1 * p2, gn, gn, -1)
+    attn, mid = gene_attention_maps(W, cfg, r)
+    out = pathway_readout(attn, mid, glst)
+    z = out.shape[-1] // (gn * gn)
+    nz = n // b
+    t = out.reshape(nz, b, p1, p2, out.shape[1], z, gn, gn).permute(1, 0, 5, 4, 2, 6, 3, 7)
+    t = t.reshape(b, nz * z, out.shape[1], p1 * gn, p2 * gn)
+    pad = gn // 2
+    return t[:, :, :, pad:-pad, pad:-pad].half()

@@ -98,3 +98,16 @@ def test_attention_maps_vs_reference():
     assert torch.equal(mid.cpu(), torch.from_numpy(gold["mid"]))
     g = attn[:, :, [75, 191]][:, :, :, [75, 191]].cpu()
     assert torch.allclose(g, torch.from_numpy(gold["attn_glst"]), atol=1e-7, rtol=1e-4)
+
+
+def test_attention_driver_readout_vs_reference():
+    """test_attn `--calc_attn` per-tile output (K18) through the HIP attention-map model."""
+    from teramind_amd.attn_maps import PATHWAYS, run_attn_batch
+    gold = torch.from_numpy(np.load(os.path.join(G, "attn_readout.npz"))["out"].astype(np.float32))
+    cfg = PathConfig()
+    m = GeneAttnModel(cfg, DEV).load_state_dict(util.state_dict(cfg, vis_only=True), strict=False)
+    tile = synth.gene_counts("attn/tile", (1, 20, 20, 26000), 0, density=0.05)
+    out = run_attn_batch(m, tile.to(DEV), PATHWAYS["GLUT"])
+    assert out.dtype == torch.float16 and out.shape == (1, 50, 8, 16, 16)
+    # fp16 storage: one ulp at |x| <= 4 is 2e-3; the softmax weights themselves agree to 1e-7
+    assert (out[0].float().cpu() - gold).abs().max() <= 2e-3

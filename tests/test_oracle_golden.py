@@ -100,3 +100,14 @@ def test_attention_maps_vs_reference_fixture():
     assert torch.allclose(attn[:, 0], torch.from_numpy(gold["attn_b0"]), atol=1e-7, rtol=1e-5)
     assert torch.equal(mid, torch.from_numpy(gold["mid"]))
     assert torch.allclose(attn[:, :, [75, 191]][:, :, :, [75, 191]], torch.from_numpy(gold["attn_glst"]), atol=1e-7, rtol=1e-5)
+
+
+def test_attention_driver_readout_vs_reference_fixture():
+    """K18 (test_attn.py:404-431): the fixture is what the reference's own Tester._run_batch saved."""
+    gold = np.load(os.path.join(G, "attn_readout.npz"))["out"]
+    cfg = PathConfig()
+    tile = synth.gene_counts("attn/tile", (1, 20, 20, 26000), 0, density=0.05)
+    with torch.inference_mode():
+        out = tc.attn_tile_readout(util.state_dict(cfg, vis_only=True), tc.oracle_config_from(cfg), tile, [75, 191])
+    assert out.dtype == torch.float16 and tuple(out.shape[1:]) == gold.shape
+    assert torch.equal(out[0].float(), torch.from_numpy(gold.astype(np.float32)))
