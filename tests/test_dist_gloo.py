@@ -55,7 +55,7 @@ def _worker(rank, world, port, q):
     try:
         sw = make_sweep(rank, world)
         out = sw.test().clone()
-        q.put((rank, sw.r0, sw.r1, out))
+        q.put((rank, sw.r0, sw.r1, out.numpy()))     # by value: the worker may exit before the parent reads
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -86,7 +86,7 @@ def test_row_sharded_sweep_equals_single_rank(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, r0, r1, out in got:
-        assert torch.equal(out, ref[:, r0 * 256:r1 * 256, :]), f"rank {rank} rows [{r0},{r1}) differ from the single-rank sweep"
+        assert torch.equal(torch.from_numpy(out), ref[:, r0 * 256:r1 * 256, :]), f"rank {rank} rows [{r0},{r1}) differ from the single-rank sweep"
 
 
 
