@@ -207,7 +207,7 @@ def main():
                          "conv27_share_of_step_time": round(prof["total_ms"] / (1e3 * dt), 4),
                          "whole_step_needed_tflops": round((NEEDED_GFLOP_PER_PATCH_STEP if P == 1 else 202.6) * value / world / 1e3, 3)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the host cores are shared at N>1)
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(out), flush=True)
     if world > 1:
