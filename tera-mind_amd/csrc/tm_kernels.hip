@@ -1232,6 +1232,146 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
   }
 }
 
+// ---- MFMA form for T = 128 tokens per window (the resolution-16 AttnBlocks) ---------------------------
+// S = Qn.Kn^T and O = P.V both run on v_mfma_f32_32x32x2_f32 (exact fp32); the softmax row reduction is a
+// wave-shuffle butterfly over the 32 lanes that hold a row's 32 columns.  Wave w owns query rows [32w, 32w+32).
+//   QK^T : A = Q (rows = queries), B = K (cols = keys); both fragments are float4 global loads of 4 channels of
+//          one token (lanes 0-31: channels 0-3, lanes 32-63: channels 4-7 of the 8-channel block), q/k RMSNorm
+//          weights folded into the K fragment, the two rstd factors applied to the 32x32 result.
+//   P.V  : computed as O^T = V^T.P^T so that a lane owns ONE token and 4 consecutive channels per accumulator
+//          quad (same coalesced CB8 / bf16 store as the conv epilogue); P goes through LDS row-major, V is
+//          staged transposed ([channel][token]) 32 channels at a time.
+struct WinLds {
+  static constexpr int PS = 132;                 // row pitch (floats): b128 fragment reads conflict free
+  static constexpr int FLOATS = 128 * PS + 32 * PS + 3 * 128 + 512;
+};
+
+__global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
+  constexpr int T = 128, PS = WinLds::PS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* P = sm;                       // [T][PS]
+  float* Vt = P + T * PS;              // [32][PS]
+  float* rq = Vt + 32 * PS;            // [T]
+  float* rk = rq + T;                  // [T]
+  int* tokoff = (int*)(rk + T);        // [T]
+  float* w2 = (float*)(tokoff + T);    // [C] q_norm.weight * k_norm.weight (C <= 512)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int n = blockIdx.x >> 2, win = blockIdx.x & 3;
+  const int wy = win >> 1, wx = win & 1;
+  const int S = a.S, hs = S / 2, C = a.C;
+  if (tid < T) {
+    const int z = tid / (hs * hs);
+    const int r = tid - z * hs * hs;
+    const int yl = r / hs, xl = r - yl * hs;
+    tokoff[tid] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
+  __syncthreads();
+  const float* qb = a.q + (long)n * a.q_ns;
+  const float* kb = a.k + (long)n * a.k_ns;
+  const float* vb = a.v + (long)n * a.v_ns;
+  {
+    const bool isq = tid < T;
+    const int t = isq ? tid : tid - T;
+    const float* p = (isq ? qb : kb) + tokoff[t];
+    float ss = 0.f;
+    for (int cb = 0; cb < C / 8; ++cb) {
+      const f32x4 a0 = *(const f32x4*)(p + (long)cb * a.plane), a1 = *(const f32x4*)(p + (long)cb * a.plane + 4);
+      ss += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] + a1[0] * a1[0] + a1[1] * a1[1] +
+            a1[2] * a1[2] + a1[3] * a1[3];
+    }
+    const float r = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+    if (isq) rq[t] = r; else rk[t] = r;
+  }
+  __syncthreads();
+
+  // ---- S = Q.K^T ----
+  f32x16 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  const float* qp = qb + tokoff[wv * 32 + i32] + 4 * h;
+  const float* kp[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) kp[ct] = kb + tokoff[ct * 32 + i32] + 4 * h;
+  for (int cb = 0; cb < C / 8; ++cb) {
+    const long po = (long)cb * a.plane;
+    const f32x4 qf = *(const f32x4*)(qp + po);
+    const f32x4 wf = *(const f32x4*)(w2 + cb * 8 + 4 * h);
+    f32x4 kf[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) kf[ct] = *(const f32x4*)(kp[ct] + po) * wf;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kk], kf[ct][kk], acc[ct], 0, 0, 0);
+  }
+  // ---- scale, softmax over keys (columns = lanes of this 32-lane half x 4 column tiles) ----
+  const float inv_c = 1.0f / (float)C;                   // (q*scale).k*scale, scale = C^-1/2 (MBAblocks.py:571-577)
+  float rkc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) rkc[ct] = rk[ct * 32 + i32] * inv_c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D layout of the 32x32 MFMA
+    const float rqr = rq[wv * 32 + row];
+    float m = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { acc[ct][r] *= rqr * rkc[ct]; m = fmaxf(m, acc[ct][r]); }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float ssum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { acc[ct][r] = expf(acc[ct][r] - m); ssum += acc[ct][r]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) P[(wv * 32 + row) * PS + ct * 32 + i32] = acc[ct][r] * inv;
+  }
+  // ---- O^T = V^T.P^T, 32 channels at a time ----
+  const float* pfrag = P + (wv * 32 + i32) * PS + 4 * h;          // B operand: P[t_j][u0 + 4h ..]
+  const float* vfrag = Vt + i32 * PS + 4 * h;                      // A operand: Vt[c_i][u0 + 4h ..]
+  const int myoff = tokoff[wv * 32 + i32];
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    __syncthreads();                                               // Vt free (and, first time, P complete)
+    for (int it = tid; it < T * 4; it += 256) {                    // (token u, 8-channel block) -> transposed store
+      const int u = it & (T - 1), cbi = it >> 7;
+      const float* p = vb + tokoff[u] + (long)(c0 / 8 + cbi) * a.plane;
+      const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
+      float* d = Vt + (cbi * 8) * PS + u;
+      d[0 * PS] = v0[0]; d[1 * PS] = v0[1]; d[2 * PS] = v0[2]; d[3 * PS] = v0[3];
+      d[4 * PS] = v1[0]; d[5 * PS] = v1[1]; d[6 * PS] = v1[2]; d[7 * PS] = v1[3];
+    }
+    __syncthreads();
+    f32x16 oc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oc[r] = 0.f;
+#pragma unroll 4
+    for (int u0 = 0; u0 < T; u0 += 8) {
+      const f32x4 af = *(const f32x4*)(vfrag + u0), bf = *(const f32x4*)(pfrag + u0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) oc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], oc, 0, 0, 0);
+    }
+    // lane = token (wv*32 + i32); accumulator quad g = channels c0 + 8g + 4h .. +3
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long eo = myoff + (long)(c0 / 8 + g) * a.plane + 4 * h;
+      if (a.o_h) {
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        bf16x4_t ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = (__bf16)oc[4 * g + j];
+        *(bf16x4_t*)(a.o_h + (long)n * a.o_h_ns + eo) = ob;
+      } else {
+        *(f32x4*)(a.o + (long)n * a.o_ns + eo) = f32x4{oc[4 * g + 0], oc[4 * g + 1], oc[4 * g + 2], oc[4 * g + 3]};
+      }
+    }
+  }
+}
+
 template <int T>
 static hipError_t launch_win(const WinArgs& a, int N, hipStream_t s) {
   const size_t lds = ((size_t)3 * T + 2 * 16 * T + (size_t)T * (T + 4) + 16 * 128) * sizeof(float);
@@ -1254,6 +1394,17 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
   a.C = q.Cb * 8; a.Z = q.Z; a.S = q.H; a.plane = q.plane();
   if (a.C % 128 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
+  if (T == 128 && a.C <= 512) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)WinLds::FLOATS * sizeof(float);
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)window_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(q.N * 4), dim3(256), lds, s, a);
+    return hipGetLastError();
+  }
   if (T == 128) return launch_win<128>(a, q.N, s);
   if (T == 32) return launch_win<32>(a, q.N, s);
   return hipErrorInvalidValue;
