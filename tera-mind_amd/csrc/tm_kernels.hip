@@ -1052,7 +1052,7 @@ hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, cons
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gene_attn_kernel, dim3(B, B >= 256 ? 1 : 2), dim3(64 * GENE_WAVES), lds, s, a);
+  hipLaunchKernelGGL(gene_attn_kernel, dim3(B, 2), dim3(64 * GENE_WAVES), lds, s, a);
   return hipGetLastError();
 }
 
@@ -1296,13 +1296,23 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
   const float* kp[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) kp[ct] = kb + tokoff[ct * 32 + i32] + 4 * h;
+  // fragments of channel block cb+1 are in flight while block cb's 16 MFMAs issue (one workgroup per CU: nothing
+  // else would hide the L2 round trip)
+  f32x4 qn = *(const f32x4*)qp, kn[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const f32x4*)kp[ct];
   for (int cb = 0; cb < C / 8; ++cb) {
-    const long po = (long)cb * a.plane;
-    const f32x4 qf = *(const f32x4*)(qp + po);
+    const f32x4 qf = qn;
     const f32x4 wf = *(const f32x4*)(w2 + cb * 8 + 4 * h);
     f32x4 kf[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) kf[ct] = *(const f32x4*)(kp[ct] + po) * wf;
+    for (int ct = 0; ct < 4; ++ct) kf[ct] = kn[ct] * wf;
+    if (cb + 1 < C / 8) {
+      const long po = (long)(cb + 1) * a.plane;
+      qn = *(const f32x4*)(qp + po);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const f32x4*)(kp[ct] + po);
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -1335,15 +1345,26 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
   const float* pfrag = P + (wv * 32 + i32) * PS + 4 * h;          // B operand: P[t_j][u0 + 4h ..]
   const float* vfrag = Vt + i32 * PS + 4 * h;                      // A operand: Vt[c_i][u0 + 4h ..]
   const int myoff = tokoff[wv * 32 + i32];
+  // V chunk staging: thread owns items (u, cbi) = (tid & 127, tid >> 7) and (tid & 127, 2 + (tid >> 7)); the next
+  // chunk's two 32-byte pieces are loaded into registers before the current chunk's MFMAs
+  const int su = tid & (T - 1), scb = tid >> 7;
+  const float* vsrc = vb + tokoff[su] + (long)scb * a.plane;
+  f32x4 vr[4];
+  vr[0] = *(const f32x4*)vsrc; vr[1] = *(const f32x4*)(vsrc + 4);
+  vr[2] = *(const f32x4*)(vsrc + 2 * a.plane); vr[3] = *(const f32x4*)(vsrc + 2 * a.plane + 4);
   for (int c0 = 0; c0 < C; c0 += 32) {
     __syncthreads();                                               // Vt free (and, first time, P complete)
-    for (int it = tid; it < T * 4; it += 256) {                    // (token u, 8-channel block) -> transposed store
-      const int u = it & (T - 1), cbi = it >> 7;
-      const float* p = vb + tokoff[u] + (long)(c0 / 8 + cbi) * a.plane;
-      const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
-      float* d = Vt + (cbi * 8) * PS + u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                         // transposed store [channel][token]
+      float* d = Vt + ((scb + 2 * half) * 8) * PS + su;
+      const f32x4 v0 = vr[2 * half], v1 = vr[2 * half + 1];
       d[0 * PS] = v0[0]; d[1 * PS] = v0[1]; d[2 * PS] = v0[2]; d[3 * PS] = v0[3];
       d[4 * PS] = v1[0]; d[5 * PS] = v1[1]; d[6 * PS] = v1[2]; d[7 * PS] = v1[3];
+    }
+    if (c0 + 32 < C) {
+      const float* p = vsrc + (long)((c0 + 32) / 8) * a.plane;
+      vr[0] = *(const f32x4*)p; vr[1] = *(const f32x4*)(p + 4);
+      vr[2] = *(const f32x4*)(p + 2 * a.plane); vr[3] = *(const f32x4*)(p + 2 * a.plane + 4);
     }
     __syncthreads();
     f32x16 oc;
