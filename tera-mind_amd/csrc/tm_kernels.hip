@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
     __syncthreads();
     if (cb + 1 < a.Cbi) load_stage(cb + 1);
 
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int zi = 0; zi < NZI; ++zi) {
 #pragma unroll
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   }
   conv_epilogue<WM>(a, acc, nt, h, on, ooff, 2 * S);
 }
