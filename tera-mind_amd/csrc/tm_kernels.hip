@@ -1033,6 +1033,241 @@ __global__ __launch_bounds__(64 * GENE_WAVES) void gene_attn_kernel(GeneArgs a) 
   }
 }
 
+// ---- MFMA form of the gene-gene attention block --------------------------------------------------------
+// Everything is computed TRANSPOSED (features / keys on the rows, the 32 genes of a query block on the
+// columns), so that each 32x32 result tile -- column = lane, rows = accumulator registers -- is directly
+// the B operand of the next product, which always sums over the previous result's ROW index:
+//   q^T = Wq.tok^T   ->  S^T = qn.qn^T (keys x queries)  ->  softmax over rows (in-lane + one xor-32 shuffle)
+//   PT^T = tok^T.P^T ->  ov^T = Wv.PT^T  ->  op^T = Wp.ov^T  ->  norm2  ->  y1^T = W1.h^T  ->  y2^T = W2.gelu(y1^T)
+// The A operands are weight / token fragments: lanes = rows, contiguous in the pre-transposed weight
+// matrices ([in][out]) and in the token image.  k pairs are (row r of the lower half, row r + 4 of the upper
+// half) of an accumulator register -- any pairing is valid as long as A uses the same one.
+// One workgroup per patch (x gridDim.y query-block shares), 4 waves, wave w owns query blocks w, w+4.
+#define GTP 68                                           // LDS row pitch (floats) of the token / q images
+#define GROWS 232                                        // rows kept in LDS (genes padded to a multiple of 8)
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256) void gene_attn_mfma_kernel(GeneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* tok = sm;                       // [GROWS][GTP]
+  float* qn = tok + GROWS * GTP;         // [GROWS][GTP]
+  float* cst = qn + GROWS * GTP;         // bq 64 | qnorm 64 | bv 64 | bp 64 | norm2 64 | b2 64 | b1 256
+  const int G = a.G, Gb = (G + 7) / 8;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int n = blockIdx.x;
+  const int gg = a.gn * a.gn;
+  const long rbase = (long)n * gg * a.zs * 500;
+  for (int i = tid; i < GROWS * GENE_D; i += 256) {
+    const int d = i / GROWS, g = i - d * GROWS;
+    const int z = d / gg, hw = d - z * gg;
+    float v = 0.f;
+    if (g < G && z >= a.zlo && z < a.zhi) v = a.rna[rbase + ((long)hw * a.zs + z) * 500 + g];
+    tok[g * GTP + d] = v;
+  }
+  if (tid < 64) {
+    cst[tid] = a.w.bq[tid]; cst[64 + tid] = a.w.qnorm[tid];
+    if (a.out_tok) {
+      cst[128 + tid] = a.w.bv[tid]; cst[192 + tid] = a.w.bp[tid]; cst[256 + tid] = a.w.norm2[tid]; cst[320 + tid] = a.w.b2[tid];
+    }
+  }
+  if (a.out_tok) cst[384 + tid] = a.w.b1[tid];
+  __syncthreads();
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- (1) q^T[j][g] = Wq[j][:] . tok[g][:] + bq[j];  qn = RMSNorm over j (rows) * w ----
+  for (int gt = wv; gt < 8; gt += 4) {
+    const int g = gt * 32 + i32;
+    // the weight fragments are loop invariant: without laundering the pointer LICM hoists all of them out of the
+    // loop (over a thousand live registers for the whole kernel) and spills
+    const float* wq_t = a.w.wq_t;
+    asm volatile("" : "+s"(wq_t));
+    f32x16 qa[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[jt][r] = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < GENE_D; k0 += 8) {
+      const f32x4 bf = (g < GROWS) ? *(const f32x4*)(tok + g * GTP + k0 + 4 * h) : zero4;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* wrow = wq_t + (k0 + 4 * h + kk) * GENE_D + i32;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) qa[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[jt * 32], bf[kk], qa[jt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { qa[jt][r] += cst[jt * 32 + mfma_row(r, h)]; ss += qa[jt][r] * qa[jt][r]; }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / GENE_D) + TM_EPS);
+    if (g < GROWS) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int j0 = jt * 32 + 8 * q4 + 4 * h;
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = cst[64 + j0 + c] * (qa[jt][4 * q4 + c] * rstd);
+          *(f32x4*)(qn + g * GTP + j0) = o;
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- per query block of 32 genes ----
+  for (int qb = wv + 4 * blockIdx.y; qb < 8; qb += 4 * gridDim.y) {
+    const int g = qb * 32 + i32;                          // this lane's gene (column)
+    const bool gok = g < G;
+    const float *wv_t = a.w.wv_t, *wp_t = a.w.wp_t, *w1_t = a.w.w1_t, *w2_t = a.w.w2_t;
+    asm volatile("" : "+s"(wv_t), "+s"(wp_t), "+s"(w1_t), "+s"(w2_t));
+    // (2) S^T[u][g] = qn[u].qn[g] / 64
+    f32x16 sacc[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+    for (int d0 = 0; d0 < GENE_D; d0 += 8) {
+      const f32x4 bf = (g < GROWS) ? *(const f32x4*)(qn + g * GTP + d0 + 4 * h) : zero4;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const int u = kt * 32 + i32;
+        const f32x4 af = (u < GROWS) ? *(const f32x4*)(qn + u * GTP + d0 + 4 * h) : zero4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], sacc[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);         // bound load hoisting: the unrolled body would otherwise spill
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = kt * 32 + mfma_row(r, h);
+        sacc[kt][r] = (u < G) ? sacc[kt][r] * 0.015625f : -INFINITY;      // (q*scale).k*scale, scale = 1/8
+        m = fmaxf(m, sacc[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float ssum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[kt][r] = expf(sacc[kt][r] - m); ssum += sacc[kt][r]; }
+    __builtin_amdgcn_sched_barrier(0);
+    ssum += __shfl_xor(ssum, 32, 64);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][r] = sacc[kt][r] / ssum;
+    if (a.attn_map && gok) {
+      float* mp = a.attn_map + ((long)n * G + g) * G;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = kt * 32 + mfma_row(r, h);
+          if (u < G) mp[u] = sacc[kt][r];
+        }
+    }
+    if (!a.out_tok) continue;
+    // (3) PT^T[d][g] = sum_u tok[u][d] P[g][u]      (B = softmax tile registers)
+    f32x16 pt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pt[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = kt * 32 + mfma_row(r, h);
+        const float* trow = tok + u * GTP + i32;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const float av = (u < GROWS) ? trow[dt * 32] : 0.f;
+          pt[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sacc[kt][r], pt[dt], 0, 0, 0);
+        }
+        if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    // (4) ov^T = Wv.PT^T + bv, (5) op^T = Wp.ov^T + bp   (weights pre-transposed [in][out]: lanes = out rows)
+    f32x16 ov[2], op[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ov[jt][r] = cst[128 + jt * 32 + mfma_row(r, h)]; op[jt][r] = cst[192 + jt * 32 + mfma_row(r, h)]; }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* wrow = wv_t + (dt * 32 + mfma_row(r, h)) * GENE_D + i32;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) ov[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[jt * 32], pt[dt][r], ov[jt], 0, 0, 0);
+        if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* wrow = wp_t + (dt * 32 + mfma_row(r, h)) * GENE_D + i32;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) op[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[jt * 32], ov[dt][r], op[jt], 0, 0, 0);
+        if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    // (6) norm2 over the 64 features (rows)
+    float ss = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ss += op[jt][r] * op[jt][r];
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / GENE_D) + TM_EPS);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[jt][r] = cst[256 + jt * 32 + mfma_row(r, h)] * (op[jt][r] * rstd);
+    // (7) MLP: y1^T = W1.h^T + b1 (256 rows), tanh-GELU, y2^T = W2.y1^T + b2
+    f32x16 y2[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y2[jt][r] = cst[320 + jt * 32 + mfma_row(r, h)];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      f32x16 y1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y1[r] = cst[384 + mt * 32 + mfma_row(r, h)];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1_t[(jt * 32 + mfma_row(r, h)) * 256 + mt * 32 + i32], op[jt][r], y1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y1[r] = gelu_tanh_f(y1[r]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* wrow = w2_t + (mt * 32 + mfma_row(r, h)) * GENE_D + i32;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) y2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[jt * 32], y1[r], y2[jt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (gok) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.out_tok[gene_tok_idx(n, g, jt * 32 + mfma_row(r, h), Gb)] = y2[jt][r];
+    }
+  }
+}
+
 static size_t gene_lds_bytes(int G) {
   const int Gp = (G + 63) / 64 * 64;
   size_t a = ((size_t)G * GENE_D + (size_t)G * GENE_QP + GENE_WAVES * Gp) * sizeof(float);
@@ -1053,6 +1288,17 @@ hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, cons
     hipError_t e = hipFuncSetAttribute((const void*)gene_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
+  }
+  if (G <= GROWS) {                                   // MFMA form (the checkpoint config: G = 229)
+    const size_t lds2 = ((size_t)2 * GROWS * GTP + 640) * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute((const void*)gene_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(gene_attn_mfma_kernel, dim3(B, B >= 256 ? 1 : 2), dim3(256), lds2, s, a);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL(gene_attn_kernel, dim3(B, 2), dim3(64 * GENE_WAVES), lds, s, a);
   return hipGetLastError();
