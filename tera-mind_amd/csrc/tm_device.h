@@ -54,15 +54,16 @@ struct ConvArgs {
   long yh_nstride = 0;
 };
 
-template <int WM>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][WM], int nt, int h,
+// acc[ct][mt]: cout tile ct (32 couts) x voxel tile mt; cob0 = first 8-cout block of acc[0]
+template <int WM, int WN = 2>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WN][WM], int nt, int h,
                                               const int (&on)[WM], const int (&ooff)[WM], int S_out) {
   // ooff: in-plane float offset of the voxel in the OUTPUT plane geometry (or -1)
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < WN; ++ct) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int cob = nt * 8 + ct * 4 + g;
+      const int cob = nt * (4 * WN) + ct * 4 + g;
       if (cob >= a.Cob) continue;
       const f32x4 bv = *(const f32x4*)(a.bias + (long)cob * 8 + 4 * h);
 #pragma unroll

@@ -173,15 +173,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
 // Replaces the skip_connection Conv3d(k=1) (model/MBAblocks.py:220-224) and every nn.Linear
 // of AttnBlock / Attention / Mlp applied to '(z h w) c' tokens (model/MBAblocks.py:465,
 // 538-544; timm Mlp fc1/fc2).
-template <int WM>
+// WN = cout tiles of 32 per wave: 2 (64-cout workgroup tile) or 4 (128-cout tile: half the activation bytes per
+// FLOP -- at 64 couts this kernel is bound by the L2 -> LDS staging rate, not by the matrix pipe)
+template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
   constexpr int MV = 4 * WM * 32;
   constexpr int KC = 4;
   constexpr int XP = KC * MV * 2 / 256;       // x pieces per thread
-  constexpr int WP = KC * 64 * 2 / 256;       // = 2
-  __shared__ __attribute__((aligned(16))) float lds[KC * 512 + KC * MV * 8];
-  float* lw = lds;
-  float* lx = lds + KC * 512;
+  constexpr int NT64 = WN / 2;                // 64-cout weight tiles per workgroup
+  constexpr int WP = NT64 * KC * 64 * 2 / 256;
+  __shared__ __attribute__((aligned(16))) float lds[NT64 * KC * 512 + KC * MV * 8];
+  float* lw = lds;                            // [NT64][KC][64][8]
+  float* lx = lds + NT64 * KC * 512;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -208,7 +211,8 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
     }
     xoff[k] = off;
   }
-  const float* wsrc = a.w + (long)nt * a.Cbi * 512 + tid * 4;
+  // piece i = tid + k*256 of the weight stage: 64-cout tile i / (KC*128), then [KC][64][2] inside it
+  const float* wsrc = a.w + (long)nt * NT64 * a.Cbi * 512;
 
   int xb[WM], on[WM], ooff[WM];
 #pragma unroll
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
   }
   const int wb = i32 * 8 + 4 * h;
 
-  f32x16 acc[2][WM];
+  f32x16 acc[WN][WM];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
@@ -242,9 +246,10 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < WP; ++k) {
-      const int i = tid + k * 256;             // piece index within [KC][64][2]
-      const int cb = cb0 + i / 128;
-      wr[k] = (cb < a.Cbi) ? *(const f32x4*)(wsrc + (long)cb0 * 512 + k * 1024) : zero4;
+      const int i = tid + k * 256;
+      const int t64 = i / (KC * 128), j = i - t64 * (KC * 128);
+      const int cb = cb0 + j / 128;
+      wr[k] = (cb < a.Cbi) ? *(const f32x4*)(wsrc + ((long)t64 * a.Cbi + cb0) * 512 + j * 4) : zero4;
     }
   };
 
@@ -259,21 +264,21 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
     if (cb0 + KC < a.Cbi) load_stage(cb0 + KC);
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      f32x4 wf[2], xf[WM];
-      wf[0] = *(const f32x4*)(lw + kc * 512 + wb);
-      wf[1] = *(const f32x4*)(lw + kc * 512 + 256 + wb);
+      f32x4 wf[WN], xf[WM];
+#pragma unroll
+      for (int ct = 0; ct < WN; ++ct) wf[ct] = *(const f32x4*)(lw + (ct >> 1) * (KC * 512) + kc * 512 + (ct & 1) * 256 + wb);
 #pragma unroll
       for (int mt = 0; mt < WM; ++mt) xf[mt] = *(const f32x4*)(lx + kc * MV * 8 + xb[mt]);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
           for (int mt = 0; mt < WM; ++mt)
             acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][kk], xf[mt][kk], acc[ct][mt], 0, 0, 0);
     }
   }
-  conv_epilogue<WM>(a, acc, nt, h, on, ooff, 0);
+  conv_epilogue<WM, WN>(a, acc, nt, h, on, ooff, 0);
 }
 
 size_t conv_pack_floats(int Cout, int Cbi, int taps) {
@@ -329,12 +334,16 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
     if (L.flags & EPI_UP2) return hipErrorInvalidValue;
     if (L.y.H != L.x.H || L.y.Z != L.x.Z) return hipErrorInvalidValue;
     int variant = L.tile_variant ? L.tile_variant : ((vox / 256) * a.ntile >= 512 ? 2 : 1);
-    if (variant == 2) {
+    if (variant == 2 && (a.ntile & 1) == 0 && (vox / 256) * (a.ntile / 2) >= 512) {
+      const long mt = (vox + 255) / 256;                  // 128-cout x 256-voxel workgroups
+      a.ntile /= 2;
+      hipLaunchKernelGGL((conv1_mfma<2, 4>), dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
+    } else if (variant == 2) {
       const long mt = (vox + 255) / 256;
-      hipLaunchKernelGGL(conv1_mfma<2>, dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv1_mfma<2, 2>), dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
     } else {
       const long mt = (vox + 127) / 128;
-      hipLaunchKernelGGL(conv1_mfma<1>, dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((conv1_mfma<1, 2>), dim3((unsigned)(mt * a.ntile)), dim3(256), 0, s, a);
     }
     return hipGetLastError();
   }
