@@ -141,6 +141,24 @@ int tm_gene_attn(tm_model* m, const void* rna_dense, int B, void* attn_out, void
 
 int tm_model_destroy(tm_model* m);
 
+/* ---- tile I/O either side of the path ----------------------------
+ * tm_gene_tile_dense replaces MBADataset_tst._getgene + _pad_gn (utils/MBADataset_tst.py:65-91) and the
+ * sparse->dense step of BeatGANsUNetModel.get_rna (model/unet_ours.py:301-306) for one gene tile:
+ *   crd  int32 [3][nnz] device: (h, w, channel) of the tile's COO transcript counts, h/w in pixels of the
+ *        +-128-px padded ROI, channel = slice*500 + gene;   dat fp32 [nnz] device: counts
+ *   out  fp32 [gsz][gsz][chan_in + 2*zpad_ch] device: out[h/gblk + shift_h][w/gblk + shift_w][zpad_ch + c] += dat
+ *        for every entry whose cell lands inside the gsz x gsz grid; everything else is zero.
+ * The reference values are gblk=16, shift = pad/gblk - (roi - roio)/gblk = -6, gsz=20, chan_in=25000,
+ * zpad_ch = Z_PAD[rna_slc]*500.  Counts are integers, so the result is independent of the order of the adds. */
+int tm_gene_tile_dense(const int32_t* crd, const void* dat, int64_t nnz, int gblk, int shift_h, int shift_w,
+                       int gsz, int chan_in, int zpad_ch, void* out, void* stream);
+
+/* Host-side decoder of one Blosc-1 frame (lz4 codec, optional byte shuffle): the chunk encoding zarr 2.14.1 /
+ * numcodecs 0.15.0 use by default for the state tiles the reference writes with zarr.save_array
+ * (test_brn.py:225) and reads back with zarr.load (utils/MBADataset_tst.py:60, infer_brn.py:76).
+ * dst == NULL: only *out_bytes (the decoded size) is set.  No GPU involved. */
+int tm_blosc_decompress(const void* src, size_t src_bytes, void* dst, size_t dst_cap, size_t* out_bytes);
+
 /* Measurement hooks (bench.py): while enabled, every launch of the dominant kernel
  * (conv27_mfma, the 3x3x3 implicit-GEMM conv) inside tm_unet_forward is bracketed by two
  * hipEvents recorded on the forward's stream.  tm_profile_collect synchronises on the last

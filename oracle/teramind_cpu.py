@@ -563,3 +563,43 @@ def attn_tile_readout(W, cfg: OracleConfig, rna_tile: Tensor, glst: Sequence[int
     t = t.reshape(b, nz * z, out.shape[1], p1 * gn, p2 * gn)
     pad = gn // 2
     return t[:, :, :, pad:-pad, pad:-pad].half()
+
+
+# ------------------------------------------------------------------------------------------
+# Tile I/O either side of the path.  The reference module needs the real `zarr` and
+# `sparse` packages (absent here), so this restatement is pinned by hand-computed known answers
+# (tests/test_oracle_golden.py), not by a run of the reference.
+def gene_tile_dense(data, coords, shape, roi, roio, gblk: int = 16, pad: int = 32, size: int = 256,
+                    spad: int = 1):
+    """utils/MBADataset_tst.py:65-79 `_getgene` (gblk x gblk block sum; channel shift by spad*500 and
+    widening by spad*1000), :81-91 `_pad_gn` (cell shift psz - (roi - roio)//gblk, crop to gsz x gsz), then
+    the dense tensor the model builds from the COO triple (model/unet_ours.py:301-306).
+    Returns float32 [gsz, gsz, shape[2] + spad*1000]."""
+    import numpy as np
+    data = np.asarray(data).astype(float).astype(np.float32)          # `_to_torch`: astype(float) -> FloatTensor
+    crd = np.asarray(coords).astype(np.int64).copy()
+    gh, gw, ch = shape
+    assert gh % gblk == 0 and gw % gblk == 0
+    # _getgene: reshape to (gh/gblk, gblk, gw/gblk, gblk, C) and sum the two gblk axes == integer-divide the coords
+    crd[0] //= gblk
+    crd[1] //= gblk
+    crd[2] += spad * 500
+    ch_out = ch + spad * 1000
+    gsz, psz = (size + 2 * pad) // gblk, pad // gblk
+    keep = np.ones(crd.shape[1], dtype=bool)
+    for i in range(2):
+        crd[i] += psz - (roi[i * 2] - roio[i * 2]) // gblk
+        keep &= (crd[i] >= 0) & (crd[i] < gsz)
+    out = np.zeros((gsz, gsz, ch_out), dtype=np.float32)
+    np.add.at(out, (crd[0, keep], crd[1, keep], crd[2, keep]), data[keep])      # duplicates add (sparse .sum / to_dense)
+    return out
+
+
+def stitch_tile_uint8(tile_f16, slc: int = 50):
+    """infer_brn.py:77-83 with is_gen=True for one tile: '(c s) h w -> (s c) h w', then
+    `((g + 1) * 127.5).astype(np.uint8)` evaluated on the float16 array."""
+    import numpy as np
+    g = np.asarray(tile_f16, dtype=np.float16)
+    c = g.shape[0] // slc
+    g = g.reshape(c, slc, *g.shape[1:]).swapaxes(0, 1).reshape(g.shape)
+    return ((g + 1) * 127.5).astype(np.uint8)

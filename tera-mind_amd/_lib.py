@@ -53,6 +53,8 @@ SIGNATURES = {
     "tm_gene_attn_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "tm_gene_attn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tm_model_destroy": (c_int, [c_void_p]),
+    "tm_gene_tile_dense": (c_int, [c_void_p, c_void_p, C.c_int64] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "tm_blosc_decompress": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, C.POINTER(c_size_t)]),
     "tm_profile_enable": (c_int, [c_void_p, c_int]),
     "tm_profile_collect": (c_int, [c_void_p, C.POINTER(TmProfStats)]),
     "tm_op_to_cb8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -142,6 +142,49 @@ class TileSweep:
         """[C, 256, 256] -- what the reference stores as '{name}.zip' (fp16) after each step."""
         return self._centre(self.cur, lr, c)
 
+    # ---- interoperability with the reference's per-step tile directories -------------------------
+    def step_dir(self, out_dir, epoch: Optional[int] = None) -> str:
+        """'{out_dir}_{epoch}': where the reference keeps the state after `epoch` steps (test_brn.py:247)."""
+        return f"{out_dir}_{self.epoch if epoch is None else epoch}"
+
+    def save_step(self, out_dir, compressor: Optional[str] = None) -> str:
+        """Write this rank's tiles as the reference would have after `self.epoch` steps: one zarr-v2 .zip per
+        tile, float16 [(stain z), 256, 256], named '{r0}_{r1}_{c0}_{c1}.zip' (test_brn.py:222-226)."""
+        import os
+        from . import formats
+        if self.epoch == 0:
+            raise ValueError("step 0 is noise regenerated from the tile seeds; the reference stores no '_0' directory")
+        d = self.step_dir(out_dir)
+        os.makedirs(d, exist_ok=True)
+        for lr in range(self.nrows):
+            band = self.cur[:, PAD + lr * tiles.TILE:PAD + (lr + 1) * tiles.TILE, PAD:-PAD].half().cpu().numpy()
+            for c in range(self.wnm):
+                name = tiles.state_tile_name(self.row0 + self.r0 + lr, self.col0 + c)
+                formats.write_state_tile(os.path.join(d, name + ".zip"), band[:, :, c * tiles.TILE:(c + 1) * tiles.TILE],
+                                         compressor)
+        return d
+
+    def load_step(self, out_dir, epoch: int):
+        """Resume from a reference-format step directory (`--cur_epoch`, test_brn.py:290-292): read this rank's
+        tiles of '{out_dir}_{epoch}', then exchange halos.  Works on directories written by the reference
+        (Blosc-lz4 chunks) and by save_step."""
+        import os
+        import numpy as np
+        from . import formats
+        if not 0 < epoch <= self.T:
+            raise ValueError(f"epoch {epoch} outside 1..{self.T}")
+        d = self.step_dir(out_dir, epoch)
+        self.cur.fill_(-1.0)
+        for lr in range(self.nrows):
+            for c in range(self.wnm):
+                name = tiles.state_tile_name(self.row0 + self.r0 + lr, self.col0 + c)
+                a = formats.read_state_tile(os.path.join(d, name + ".zip"))
+                if a.shape != (self.chn, tiles.TILE, tiles.TILE):
+                    raise ValueError(f"{name}.zip: shape {a.shape}, expected {(self.chn, tiles.TILE, tiles.TILE)}")
+                self._centre(self.cur, lr, c).copy_(torch.from_numpy(a.astype(np.float32)))
+        self.epoch = epoch
+        self._exchange(self.cur)
+
 
 def synthetic_gene_provider(conf: PathConfig, total_slc: int = 50, density: float = 0.02, device="cpu"):
     """Config-3 synthetic genes: a [20, 20, 26000] tile seeded by the tile
@@ -157,3 +200,55 @@ def synthetic_gene_provider(conf: PathConfig, total_slc: int = 50, density: floa
             core = torch.cat((z, core, z), dim=-1)
         return core.to(device)
     return provider
+
+
+class GeneTileDir:
+    """gene_provider over a directory of the reference's gene tiles (test_brn.py:51-70 `gn_sublst` names,
+    utils/MBADataset_tst.py:65-91,140-154): '{r0}_{r1}_{c0}_{c1}_{R0}_{R1}_{C0}_{C1}.npz' COO archives of the
+    tile padded by 128 px.  The COO arrays are uploaded once and stay resident (a few MB per tile instead of
+    the 41.6 MB dense grid); every call re-densifies on the device with `tm_gene_tile_dense`
+    (block sum + halo shift + crop + z padding in one scatter pass)."""
+
+    def __init__(self, gdir, conf: PathConfig, device, total_slc: int = 50, keep_resident: bool = True):
+        import os
+        self.gdir, self.conf, self.dev = str(gdir), conf, torch.device(device)
+        self.gblk = conf.patch_size // conf.gn_sz                      # test_brn.py:282 `_blk`
+        self.gsz = (tiles.TILE + 2 * PAD) // self.gblk
+        self.chan_in = total_slc * tiles.GENES
+        self.zpad_ch = Z_PAD[conf.rna_slc] * tiles.GENES
+        self.keep, self.cache = keep_resident, {}
+        self._os = os
+
+    def path(self, row: int, col: int) -> str:
+        r0, c0, half = row * tiles.TILE, col * tiles.TILE, tiles.TILE // 2
+        v = (r0, r0 + tiles.TILE, c0, c0 + tiles.TILE, r0 - half, r0 + tiles.TILE + half, c0 - half, c0 + tiles.TILE + half)
+        return self._os.path.join(self.gdir, "_".join(str(x) for x in v) + ".npz")
+
+    def _load(self, row: int, col: int):
+        import numpy as np
+        from . import formats
+        p = self.path(row, col)
+        data, coords, shape = formats.read_gene_npz(p)
+        if len(shape) != 3 or shape[2] != self.chan_in:
+            raise ValueError(f"{p}: gene tile shape {shape}, expected [*, *, {self.chan_in}]")
+        roi, roio = formats.parse_gene_tile_name(p)
+        if shape[0] != roio[1] - roio[0] or shape[1] != roio[3] - roio[2]:
+            raise ValueError(f"{p}: array extent {shape[:2]} does not match the padded ROI in its name")
+        sh, sw = formats.gene_tile_shift(roi, roio, self.gblk, PAD)
+        crd = torch.from_numpy(np.ascontiguousarray(coords.astype(np.int32))).to(self.dev)
+        dat = torch.from_numpy(np.ascontiguousarray(np.asarray(data).astype(float).astype(np.float32))).to(self.dev)
+        return crd, dat, sh, sw
+
+    def __call__(self, row: int, col: int) -> torch.Tensor:
+        from . import _lib
+        ent = self.cache.get((row, col))
+        if ent is None:
+            ent = self._load(row, col)
+            if self.keep:
+                self.cache[(row, col)] = ent
+        crd, dat, sh, sw = ent
+        out = torch.empty((self.gsz, self.gsz, self.chan_in + 2 * self.zpad_ch), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.lib().tm_gene_tile_dense(_lib.ptr(crd), _lib.ptr(dat), dat.numel(), self.gblk, sh, sw, self.gsz,
+                                                 self.chan_in, self.zpad_ch, _lib.ptr(out), _lib.current_stream_ptr()),
+                   "tm_gene_tile_dense")
+        return out

@@ -180,4 +180,10 @@ hipError_t launch_sampler_step(const StepCoefs& c, const float* x_patches, const
 hipError_t launch_pad_patchify(const float* img, float* patches, int b, int C, int P1, int P2,
                                int ps, float pad, hipStream_t s);
 
+// ---- tile I/O (tm_io.hip) --------------------------------------------------------------
+int io_fail(int code, const char* msg);     // sets the tm_last_error() text, returns code
+hipError_t launch_gene_tile_scatter(const int32_t* crd, const float* dat, long nnz, int gblk, int shift_h, int shift_w,
+                                    int gsz, int chan_in, int zpad_ch, float* out, hipStream_t s);
+int blosc_decompress(const void* src, size_t src_bytes, void* dst, size_t dst_cap, size_t* out_bytes);
+
 }  // namespace tmk

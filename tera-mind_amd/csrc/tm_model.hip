@@ -24,6 +24,8 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// shared with tm_io.hip (same thread-local message buffer behind tm_last_error)
+int tmk::io_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (expr);                                                                    \
@@ -265,6 +267,19 @@ static int build_graph(tm_model* m) {
 
 // ------------------------------------------------------------------------------------------
 extern "C" int tm_version(void) { return TM_ABI_VERSION; }
+
+extern "C" int tm_gene_tile_dense(const int32_t* crd, const void* dat, int64_t nnz, int gblk, int shift_h, int shift_w,
+                                  int gsz, int chan_in, int zpad_ch, void* out, void* stream) {
+  if (!out || nnz < 0 || (nnz > 0 && (!crd || !dat))) return fail(TM_ERR_ARG, "null / negative argument");
+  if (gblk < 1 || gsz < 1 || chan_in < 1 || zpad_ch < 0) return fail(TM_ERR_ARG, "bad gene-tile geometry");
+  HIP_TRY(launch_gene_tile_scatter(crd, (const float*)dat, (long)nnz, gblk, shift_h, shift_w, gsz, chan_in, zpad_ch,
+                                   (float*)out, (hipStream_t)stream));
+  return TM_OK;
+}
+
+extern "C" int tm_blosc_decompress(const void* src, size_t src_bytes, void* dst, size_t dst_cap, size_t* out_bytes) {
+  return blosc_decompress(src, src_bytes, dst, dst_cap, out_bytes);
+}
 extern "C" const char* tm_last_error(void) { return g_err; }
 
 extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {

@@ -101,3 +101,25 @@ def report(name, got, ref):
     return (f"{name}: max|d|={d.max().item():.3e} mean|d|={d.mean().item():.3e} "
             f"ref absmax={ref.abs().max().item():.3e} std={ref.std().item():.3e} "
             f"nan={int(torch.isnan(got).sum())}")
+
+
+def synthetic_gene_coo(row, col, total_slc=50, nnz=20000, seed=0, size=256, dtype=np.uint16):
+    """A gene tile the way the reference stores it: COO counts over the tile padded by size/2 px,
+    shape [2*size, 2*size, total_slc*500]; duplicates and entries in the cropped margin included."""
+    rng = np.random.default_rng(seed * 1000003 + row * 1009 + col)
+    shape = (2 * size, 2 * size, total_slc * 500)
+    crd = np.stack([rng.integers(0, shape[0], nnz), rng.integers(0, shape[1], nnz), rng.integers(0, shape[2], nnz)])
+    crd[:, : nnz // 10] = crd[:, nnz // 10: 2 * (nnz // 10)]          # repeated coordinates must add up
+    data = rng.integers(1, 6, nnz).astype(dtype)
+    return data, crd.astype(np.int64), shape
+
+
+def write_gene_dir(gdir, rows, cols, total_slc=50, nnz=20000, seed=0):
+    from teramind_amd import formats, tiles
+    os.makedirs(gdir, exist_ok=True)
+    for r in rows:
+        for c in cols:
+            half = tiles.TILE // 2
+            v = (r * 256, r * 256 + 256, c * 256, c * 256 + 256, r * 256 - half, r * 256 + 256 + half, c * 256 - half, c * 256 + 256 + half)
+            data, crd, shape = synthetic_gene_coo(r, c, total_slc, nnz, seed)
+            formats.write_gene_npz(os.path.join(gdir, "_".join(map(str, v)) + ".npz"), data, crd, shape)
