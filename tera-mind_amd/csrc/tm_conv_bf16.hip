@@ -489,6 +489,7 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.y = L.y.p; a.y_nstride = L.y.nstride; a.y_plane = L.y.plane(); a.Cob = L.y.Cb;
   a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
   a.gate = L.gate ? L.gate->p : nullptr; a.gate_nstride = L.gate ? L.gate->nstride : 0;
+  a.gate_h = L.gate_h ? L.gate_h->p : nullptr; a.gate_h_nstride = L.gate_h ? L.gate_h->nstride : 0;
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = L.flags;
   a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
   ah.fuse = 0;

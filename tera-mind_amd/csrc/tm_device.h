@@ -52,6 +52,8 @@ struct ConvArgs {
   int N, S, Z, Cbi, ntile, flags;
   uint16_t* y_h = nullptr;          // optional bf16 CB8 output INSTEAD of y (strides in elements)
   long yh_nstride = 0;
+  const uint16_t* gate_h = nullptr; // optional bf16 CB8 gate instead of `gate` (same plane geometry as y)
+  long gate_h_nstride = 0;
 };
 
 // acc[ct][mt]: cout tile ct (32 couts) x voxel tile mt; cob0 = first 8-cout block of acc[0]
@@ -82,6 +84,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
         if (a.gate) {
           const f32x4 gv = *(const f32x4*)(a.gate + (long)on[mt] * a.gate_nstride + pl);
           o *= gv;
+        } else if (a.gate_h) {
+          typedef __bf16 bf16x4_g __attribute__((ext_vector_type(4)));
+          const bf16x4_g gb = *(const bf16x4_g*)(a.gate_h + (long)on[mt] * a.gate_h_nstride + pl);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] *= (float)gb[j];
         }
         if (a.res) {
           const f32x4 rv = *(const f32x4*)(a.res + (long)on[mt] * a.res_nstride + pl);

@@ -56,6 +56,12 @@ struct TVH {                        // bf16 CB8 tensor [N][Cb (even)][Z][H][W][8
   uint16_t* p = nullptr;
   int N = 0, C = 0, Cb = 0, Z = 0, H = 0, W = 0;
   long nstride = 0;
+  TVH blocks(int cb0, int ncb) const {          // channel-block slice sharing the storage
+    TVH t = *this;
+    t.p = p + (long)cb0 * Z * H * W * 8;
+    t.Cb = ncb; t.C = ncb * 8;
+    return t;
+  }
 };
 struct ConvLaunchH {
   TVH x;
@@ -65,6 +71,7 @@ struct ConvLaunchH {
   TV y;                             // fp32 CB8 output (geometry is also used for the bf16 output)
   const TV* res = nullptr;
   const TV* gate = nullptr;         // conv1 only
+  const TVH* gate_h = nullptr;      // conv1 only: bf16 gate instead of `gate`
   int flags = 0;                    // conv1 only: EPI_GELU
   uint16_t* y_h = nullptr;          // conv1 only: write bf16 CB8 INSTEAD of y (next Linear's input)
   long yh_nstride = 0;
@@ -105,6 +112,8 @@ struct PrepLaunch {
   const float* mod_scale = nullptr; // MOD_IMAGE: [b][..] row stride mod_stride; MOD_VOXEL: CB8 tensor
   const float* mod_shift = nullptr;
   long mod_stride = 0;              // MOD_IMAGE: floats per image row; MOD_VOXEL: nstride
+  const uint16_t* mod_scale_h = nullptr;   // MOD_VOXEL with a bf16 CB8 modulation tensor (instead of mod_scale/shift)
+  const uint16_t* mod_shift_h = nullptr;
   int per_image = 1;                // output patches per image (n -> image index)
   int act = 0;                      // 1 = SiLU
   float* out = nullptr;

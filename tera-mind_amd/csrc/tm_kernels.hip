@@ -528,8 +528,15 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
       }
     } else if (L.mod == MOD_VOXEL) {
       const long mo = (long)n * L.mod_stride + (long)gb * oplane + oin;
+      if (L.mod_scale_h) {
+        typedef __bf16 bf16x8_m __attribute__((ext_vector_type(8)));
+        const bf16x8_m scb = *(const bf16x8_m*)(L.mod_scale_h + mo), shb = *(const bf16x8_m*)(L.mod_shift_h + mo);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { sc[j] = L.mod_scale[mo + j]; sh[j] = L.mod_shift[mo + j]; }
+        for (int j = 0; j < 8; ++j) { sc[j] = (float)scb[j]; sh[j] = (float)shb[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = L.mod_scale[mo + j]; sh[j] = L.mod_shift[mo + j]; }
+      }
     }
     float o[8], r[8];
 #pragma unroll

@@ -706,10 +706,11 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
 }
 
 static void run_conv1_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, const TV* gate,
-                        int flags, TVH* y_h = nullptr) {
+                        int flags, TVH* y_h = nullptr, const TVH* gate_h = nullptr) {
   if (cx.dry) return;
   ConvLaunchH L;
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
+  L.gate_h = gate_h;
   if (y_h) { L.y_h = y_h->p; L.yh_nstride = y_h->nstride; }
   cx.check(launch_conv1_bf16(L, cx.s));
 }
@@ -802,10 +803,11 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
   const size_t mark = cx.top;
   const int N = x.N, Z = x.Z, S = x.H, C = w.C, cb = C / 8;
   if (cx.m->cfg.dtype == TM_DTYPE_BF16) {
-    // bf16 operands for every Linear (fp32 accumulate); residual stream x, modulation tensor, q/k/v and the
-    // softmax stay fp32.  Activations that only feed a Linear are produced directly in bf16.
+    // bf16 operands for every Linear (fp32 accumulate); the residual stream x, q/k/v and the softmax stay fp32.
+    // Activations that only feed a Linear, and the 7C modulation tensor (shift/scale/gate/cross-cond chunks), are
+    // produced directly in bf16: the cross-cond chunk is the kv Linear's input as it stands.
     const int gbe = ((w.G + 7) / 8 + 1) / 2 * 2;
-    auto prep_h = [&](const float* p, long ns, int Cbs, bool collage, const float* nw, const TV* sc, const TV* sh, int act,
+    auto prep_h = [&](const float* p, long ns, int Cbs, bool collage, const float* nw, const TVH* sc, const TVH* sh, int act,
                       TVH dst, int Creal) {
       if (cx.dry) return;
       PrepLaunch P;
@@ -813,29 +815,30 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
       P.src[0].p = p; P.src[0].nstride = ns; P.src[0].Cb = Cbs; P.src[0].collage = collage ? 1 : 0;
       P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = act; P.per_image = per_image;
       P.norm_w = nw; P.inv_c = 1.0f / (float)Creal;
-      if (sc) { P.mod = MOD_VOXEL; P.mod_scale = sc->p; P.mod_shift = sh->p; P.mod_stride = sc->nstride; }
+      if (sc) { P.mod = MOD_VOXEL; P.mod_scale_h = sc->p; P.mod_shift_h = sh->p; P.mod_stride = sc->nstride; }
       P.out_h = dst.p; P.out_h_nstride = dst.nstride; P.pad_blocks = dst.Cb - Cbs;
       cx.check(launch_prep(P, cx.s));
     };
     TVH cact = cx.tensor_h(N, gbe, Z, S);
     prep_h(cond.t.p, cond.t.nstride, cond.t.Cb, cond.collage, nullptr, nullptr, nullptr, 1, cact, w.G);
-    TV mod = cx.tensor(N, 7 * C, Z, S);
-    run_conv1_h(cx, cact, w.adah, w.ada, mod, nullptr, nullptr, 0);
-    TV sh_a = mod.blocks(0 * cb, cb), sc_a = mod.blocks(1 * cb, cb), g_a = mod.blocks(2 * cb, cb);
-    TV crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
-    TVH xa = cx.tensor_h(N, cb, Z, S), crsh = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
+    TVH mod = cx.tensor_h(N, 7 * cb, Z, S);
+    TV mod_geom = x; mod_geom.Cb = 7 * cb; mod_geom.C = 7 * C; mod_geom.p = nullptr; mod_geom.nstride = (long)7 * cb * x.plane();
+    run_conv1_h(cx, cact, w.adah, w.ada, mod_geom, nullptr, nullptr, 0, &mod);
+    // chunk order (MBAblocks.py:487): shift_msa, scale_msa, gate_msa, crss_cnd, shift_mlp, scale_mlp, gate_mlp
+    TVH sh_a = mod.blocks(0 * cb, cb), sc_a = mod.blocks(1 * cb, cb), g_a = mod.blocks(2 * cb, cb);
+    TVH crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
+    TVH xa = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
     prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
-    prep_h(crs.p, crs.nstride, cb, false, nullptr, nullptr, nullptr, 0, crsh, C);
     TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, S);
     run_conv1_h(cx, xa, w.qh, w.q, q, nullptr, nullptr, 0);
-    run_conv1_h(cx, crsh, w.kvh, w.kv, kv, nullptr, nullptr, 0);
+    run_conv1_h(cx, crs, w.kvh, w.kv, kv, nullptr, nullptr, 0);
     if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, q, cx.s, oh.p, oh.nstride));
-    run_conv1_h(cx, oh, w.projh, w.proj, x, &x, &g_a, 0);
+    run_conv1_h(cx, oh, w.projh, w.proj, x, &x, nullptr, 0, nullptr, &g_a);
     prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
     TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);
     TV h1_geom = x; h1_geom.Cb = 4 * cb; h1_geom.C = 4 * C; h1_geom.p = nullptr; h1_geom.nstride = (long)4 * cb * x.plane();
     run_conv1_h(cx, xa, w.fc1h, w.fc1, h1_geom, nullptr, nullptr, EPI_GELU, &h1);
-    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, &x, &g_m, 0);
+    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, &x, nullptr, 0, nullptr, &g_m);
     cx.top = mark;
     return;
   }
