@@ -203,6 +203,13 @@ int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_ho
 int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
                      int N, int Cin, int Cout, int Z, int S, int gelu, void* stream);
 
+/* Windowed gene-patch cross attention core (model/MBAblocks.py:551-601 between the q/k/v Linears and proj):
+ * q, k, v fp32 CB8 [N, C, Z, S, S]; qw, kw: device fp32 [C] (q_norm / k_norm weights).
+ * dtype TM_DTYPE_F32: fp32 MFMA kernels, out = fp32 CB8.  TM_DTYPE_BF16: inputs are rounded to bf16 first (what the
+ * bf16 q / kv Linears emit), out = bf16 CB8 [N][C/8][Z][S][S][8]. */
+int tm_op_window_attn(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_dev, const void* kw_dev,
+                      void* out, int N, int C, int Z, int S, int dtype, void* stream);
+
 /* Generic direct Conv3d (stem / head / RNA path), NCDHW in, NCDHW out. */
 int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N,
                       int Cin, int Cout, int Zin, int S, int kz, int ky, int kx, int pz, int py,

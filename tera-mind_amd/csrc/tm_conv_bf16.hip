@@ -403,6 +403,243 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* z
   conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 0);
 }
 
+
+// ==========================================================================================
+// Windowed cross attention core, bf16 operands (TM_DTYPE_BF16): model/MBAblocks.py:560-590 with
+// enable_flash_attn=True semantics -- q_norm / k_norm (RMSNorm over C), softmax((q*scale).(k*scale)^T), .v,
+// scale = C^-1/2, one head of width C, windows of T = Z*(S/2)^2 tokens (2 x 2 windows per patch).
+// q, k, v arrive as bf16 CB8 (written by the q / kv Linears), the result leaves as bf16 CB8 (proj's input).
+//
+//   S^T = K.Q^T  on v_mfma_f32_32x32x16_bf16: A = K (rows = keys) read as raw 16-byte fragments straight from
+//        global memory, B = Q (cols = queries) with q_norm.w * k_norm.w folded in; the two rstd factors and the
+//        scale are applied to the fp32 result.  A lane then owns ONE query and 16 x T/32 keys: the softmax
+//        reduction is in-lane plus one exchange with lane ^ 32.
+//   P -> LDS row-major [query][key] bf16 (8-byte stores of 4 consecutive keys), which is the B operand of
+//   O^T = V^T.P^T: A = V^T (rows = channels) from an LDS image transposed while staging, 64 channels per
+//        stage, double buffered.  A lane ends up with one token and 4 consecutive channels per accumulator quad:
+//        the coalesced bf16 CB8 store of the conv epilogues.
+// T = 128: one workgroup per window, wave w owns queries [32w, 32w+32).  T = 32: one workgroup per patch, one
+// window per wave.  Either way a workgroup covers 128 query and 128 key tokens.
+template <int T>
+struct WAGeo {
+  static constexpr int NW = T / 32;                 // waves per window
+  static constexpr int WPW = 4 / NW;                // windows per workgroup
+  static constexpr int PP = T * 2 + 16;             // row pitch in bytes of P and V^T rows: 16 B mod 256 B
+  static constexpr int CH = 64;                     // channels per V stage
+  static constexpr int P_BYTES = 128 * PP;          // [128 queries of the workgroup][T keys]
+  static constexpr int VT_BYTES = WPW * CH * PP;    // one stage, all windows of the workgroup
+  static constexpr int MISC_FLOATS = 128 /*tokoff*/ + 128 /*rq*/ + 128 /*rk*/ + 512 /*w2*/;
+  static constexpr int LDS_BYTES = P_BYTES + 2 * VT_BYTES + MISC_FLOATS * 4;
+};
+
+struct WinArgsH {
+  const uint16_t *q, *k, *v; long q_ns, k_ns, v_ns;
+  const float *qw, *kw;
+  uint16_t* o; long o_ns;
+  int C, S;
+  long plane;                                       // elements per channel block
+};
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
+  using G = WAGeo<T>;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Pl = smem;                                   // [128][PP]
+  unsigned char* Vt = Pl + G::P_BYTES;                        // 2 x [WPW][CH][PP]
+  int* tokoff = (int*)(Vt + 2 * G::VT_BYTES);                 // [128]: window-major, token-minor
+  float* rq = (float*)(tokoff + 128);
+  float* rk = rq + 128;
+  float* w2 = rk + 128;                                       // [C] q_norm.w * k_norm.w
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int n = (T == 128) ? (blockIdx.x >> 2) : blockIdx.x;
+  const int S = a.S, hs = S / 2, C = a.C, npair = C / 16;
+  if (tid < 128) {
+    const int win = (T == 128) ? (blockIdx.x & 3) : (tid / T);
+    const int t = tid % T;
+    const int wy = win >> 1, wx = win & 1;
+    const int z = t / (hs * hs);
+    const int r = t - z * hs * hs;
+    const int yl = r / hs, xl = r - yl * hs;
+    tokoff[tid] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
+  __syncthreads();
+  const __bf16* qb = (const __bf16*)a.q + (long)n * a.q_ns;
+  const __bf16* kb = (const __bf16*)a.k + (long)n * a.k_ns;
+  const __bf16* vb = (const __bf16*)a.v + (long)n * a.v_ns;
+  {  // RMSNorm statistics of the 128 query and 128 key tokens (fp32 sums over the bf16 values)
+    const bool isq = tid < 128;
+    const int t = tid & 127;
+    const __bf16* p = (isq ? qb : kb) + tokoff[t];
+    float ss = 0.f;
+    for (int cb = 0; cb < C / 8; ++cb) {
+      const bf16x8 v8 = *(const bf16x8*)(p + (long)cb * a.plane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)v8[j]; ss += f * f; }
+    }
+    const float r = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+    if (isq) rq[t] = r; else rk[t] = r;
+  }
+  __syncthreads();
+
+  const int wbase = (T == 128) ? 0 : wv * T;                  // first token (workgroup numbering) of this wave's window
+  const int qtok = (T == 128) ? wv * 32 + i32 : wbase + i32;  // this lane's query
+  // ---- S^T = K.Q^T ----
+  f32x16 acc[G::NW];
+#pragma unroll
+  for (int ct = 0; ct < G::NW; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  const __bf16* qp = qb + tokoff[qtok] + (long)h * a.plane;
+  const __bf16* kp[G::NW];
+#pragma unroll
+  for (int ct = 0; ct < G::NW; ++ct) kp[ct] = kb + tokoff[wbase + ct * 32 + i32] + (long)h * a.plane;
+  bf16x8 qn = *(const bf16x8*)qp, kn[G::NW];
+#pragma unroll
+  for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)kp[ct];
+  for (int kp2 = 0; kp2 < npair; ++kp2) {
+    bf16x8 qf;
+    {
+      const f32x4 wa = *(const f32x4*)(w2 + kp2 * 16 + 8 * h), wb = *(const f32x4*)(w2 + kp2 * 16 + 8 * h + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qf[j] = (__bf16)((float)qn[j] * wa[j]); qf[4 + j] = (__bf16)((float)qn[4 + j] * wb[j]); }
+    }
+    bf16x8 kf[G::NW];
+#pragma unroll
+    for (int ct = 0; ct < G::NW; ++ct) kf[ct] = kn[ct];
+    if (kp2 + 1 < npair) {
+      const long po = (long)(kp2 + 1) * 2 * a.plane;
+      qn = *(const bf16x8*)(qp + po);
+#pragma unroll
+      for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)(kp[ct] + po);
+    }
+#pragma unroll
+    for (int ct = 0; ct < G::NW; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ct], qf, acc[ct], 0, 0, 0);
+  }
+  // ---- scale + softmax over the keys of this lane's query (registers, then lane ^ 32) ----
+  {
+    const float sq = rq[qtok] / (float)C;                     // (q*scale).(k*scale), scale = C^-1/2 (MBAblocks.py:571-577)
+    float m = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < G::NW; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        acc[ct][r] *= sq * rk[wbase + key];
+        m = fmaxf(m, acc[ct][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float ssum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < G::NW; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[ct][r] = expf(acc[ct][r] - m); ssum += acc[ct][r]; }
+    ssum += __shfl_xor(ssum, 32, 64);
+    const float inv = 1.0f / ssum;
+    unsigned char* prow = Pl + (long)(wv * 32 + i32) * G::PP;
+#pragma unroll
+    for (int ct = 0; ct < G::NW; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = (__bf16)(acc[ct][4 * g + j] * inv);
+        *(bf16x4*)(prow + (ct * 32 + 8 * g + 4 * h) * 2) = pk;
+      }
+  }
+  // ---- O^T = V^T.P^T ----
+  // V staging: 512 items per stage = 64 token pairs x 8 channel blocks; thread owns items tid and tid + 256
+  const int gp = tid & 63;                                    // token pair (workgroup numbering 2gp, 2gp+1)
+  const int swin = (2 * gp) / T, st = (2 * gp) % T;
+  const __bf16* vs0 = vb + tokoff[2 * gp];
+  const __bf16* vs1 = vb + tokoff[2 * gp + 1];
+  const int scb = tid >> 6;                                   // channel blocks scb and scb + 4 of the stage
+  bf16x8 vr[4];
+  auto vload = [&](int c0) {
+    const long o0 = (long)(c0 / 8 + scb) * a.plane, o1 = o0 + 4 * a.plane;
+    vr[0] = *(const bf16x8*)(vs0 + o0); vr[1] = *(const bf16x8*)(vs1 + o0);
+    vr[2] = *(const bf16x8*)(vs0 + o1); vr[3] = *(const bf16x8*)(vs1 + o1);
+  };
+  auto vstore = [&](int buf) {
+    unsigned char* base = Vt + buf * G::VT_BYTES + swin * G::CH * G::PP + st * 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 two;
+        two[0] = vr[2 * half][j]; two[1] = vr[2 * half + 1][j];
+        *(bf16x2*)(base + ((scb + 4 * half) * 8 + j) * G::PP) = two;
+      }
+  };
+  vload(0);
+  vstore(0);
+  if (G::CH < C) vload(G::CH);
+  __syncthreads();                                            // P rows and V stage 0 visible
+  bf16x8 pf[T / 16];
+  {
+    const unsigned char* prow = Pl + (long)(wv * 32 + i32) * G::PP + 16 * h;
+#pragma unroll
+    for (int kb2 = 0; kb2 < T / 16; ++kb2) pf[kb2] = *(const bf16x8*)(prow + kb2 * 32);
+  }
+  const int myoff = tokoff[qtok];
+  const int vwin = (T == 128) ? 0 : wv;
+  __bf16* ob = (__bf16*)a.o + (long)n * a.o_ns;
+  int buf = 0;
+  for (int c0 = 0; c0 < C; c0 += G::CH) {
+    if (c0 + G::CH < C) vstore(buf ^ 1);                      // next stage's registers -> the other buffer
+    if (c0 + 2 * G::CH < C) vload(c0 + 2 * G::CH);
+    const unsigned char* vrow = Vt + buf * G::VT_BYTES + vwin * G::CH * G::PP + 16 * h;
+#pragma unroll
+    for (int ctile = 0; ctile < G::CH / 32; ++ctile) {
+      f32x16 oc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oc[r] = 0.f;
+      const unsigned char* ar = vrow + (long)(ctile * 32 + i32) * G::PP;
+#pragma unroll
+      for (int kb2 = 0; kb2 < T / 16; ++kb2)
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ar + kb2 * 32), pf[kb2], oc, 0, 0, 0);
+      // lane = token qtok; accumulator quad g = channels c0 + 32*ctile + 8g + 4h .. +3
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = (__bf16)oc[4 * g + j];
+        *(bf16x4*)(ob + myoff + (long)((c0 + 32 * ctile) / 8 + g) * a.plane + 4 * h) = o4;
+      }
+    }
+    __syncthreads();                                          // stage `buf` consumed, stage buf^1 complete
+    buf ^= 1;
+  }
+}
+
+hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, const float* qnorm_w, const float* knorm_w,
+                                   TVH o, hipStream_t s) {
+  WinArgsH a;
+  a.q = q.p; a.k = k.p; a.v = v.p; a.q_ns = q.nstride; a.k_ns = k.nstride; a.v_ns = v.nstride;
+  a.qw = qnorm_w; a.kw = knorm_w; a.o = o.p; a.o_ns = o.nstride;
+  a.C = q.Cb * 8; a.S = q.H; a.plane = (long)q.Z * q.H * q.W * 8;
+  const int T = q.Z * (q.H / 2) * (q.H / 2);
+  if (a.C % 64 || a.C > 512 || q.H != q.W || (q.H & 1) || (T != 128 && T != 32)) return hipErrorInvalidValue;
+#define TM_LAUNCHWA(T_)                                                                                     \
+  do {                                                                                                      \
+    static bool attr_set = false;                                                                           \
+    if (!attr_set) {                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)window_attn_bf16<T_>,                                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, WAGeo<T_>::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                                        \
+      attr_set = true;                                                                                      \
+    }                                                                                                       \
+    hipLaunchKernelGGL(window_attn_bf16<T_>, dim3((unsigned)(q.N * WAGeo<T_>::NW)), dim3(256),              \
+                       WAGeo<T_>::LDS_BYTES, s, a);                                                         \
+  } while (0)
+  if (T == 128) TM_LAUNCHWA(128); else TM_LAUNCHWA(32);
+#undef TM_LAUNCHWA
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 static inline uint16_t f32_to_bf16_rne(float f) {
   uint32_t u;

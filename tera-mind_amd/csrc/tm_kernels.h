@@ -90,6 +90,8 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s);
 size_t conv_bf16_pack_elems(int Cout, int Cbi);
 void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
 hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s);
+hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, const float* qnorm_w, const float* knorm_w,
+                                   TVH o, hipStream_t s);
 
 // ---- prep: concat + resample + RMSNorm(C) * w -> modulate -> act ---------------------
 struct PrepSrc {

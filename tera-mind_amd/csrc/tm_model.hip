@@ -829,10 +829,14 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     TVH crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
     TVH xa = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
     prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
-    TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, S);
-    run_conv1_h(cx, xa, w.qh, w.q, q, nullptr, nullptr, 0);
-    run_conv1_h(cx, crs, w.kvh, w.kv, kv, nullptr, nullptr, 0);
-    if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, q, cx.s, oh.p, oh.nstride));
+    // q, k, v leave their Linears as bf16 (the attention core's MFMA operands); softmax and accumulation are fp32
+    TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, S);
+    TV q_geom = x; q_geom.p = nullptr;
+    TV kv_geom = x; kv_geom.Cb = 2 * cb; kv_geom.C = 2 * C; kv_geom.p = nullptr; kv_geom.nstride = (long)2 * cb * x.plane();
+    q_geom.nstride = (long)cb * x.plane();
+    run_conv1_h(cx, xa, w.qh, w.q, q_geom, nullptr, nullptr, 0, &q);
+    run_conv1_h(cx, crs, w.kvh, w.kv, kv_geom, nullptr, nullptr, 0, &kv);
+    if (!cx.dry) cx.check(launch_window_attn_bf16(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, oh, cx.s));
     run_conv1_h(cx, oh, w.projh, w.proj, x, &x, nullptr, 0, nullptr, &g_a);
     prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
     TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);
@@ -1194,6 +1198,43 @@ extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const voi
   if (e0 != hipSuccess) return fail(TM_ERR_HIP, "launch_prep: %s", hipGetErrorString(e0));
   if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv1_bf16: %s", hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1_bf16 execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}
+extern "C" int tm_op_window_attn(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_dev,
+                                 const void* kw_dev, void* out, int N, int C, int Z, int S, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 128) return fail(TM_ERR_ARG, "C must be a multiple of 128");
+  TV q = view_cb8(const_cast<void*>(q_cb8), N, C, Z, S, S), k = view_cb8(const_cast<void*>(k_cb8), N, C, Z, S, S);
+  TV v = view_cb8(const_cast<void*>(v_cb8), N, C, Z, S, S);
+  if (dtype == TM_DTYPE_F32) {
+    TV o = view_cb8(out, N, C, Z, S, S);
+    HIP_TRY(launch_window_attn(q, k, v, (const float*)qw_dev, (const float*)kw_dev, o, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TM_OK;
+  }
+  const int cb = C / 8;
+  const long ns = (long)cb * Z * S * S * 8;
+  uint16_t* buf = nullptr;
+  HIP_TRY(hipMalloc((void**)&buf, (size_t)3 * N * ns * sizeof(uint16_t)));
+  TVH h[3];
+  const TV* src[3] = {&q, &k, &v};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+    h[i].p = buf + (size_t)i * N * ns; h[i].N = N; h[i].C = C; h[i].Cb = cb; h[i].Z = Z; h[i].H = S; h[i].W = S; h[i].nstride = ns;
+    PrepLaunch P;
+    P.nsrc = 1;
+    P.src[0].p = src[i]->p; P.src[0].nstride = src[i]->nstride; P.src[0].Cb = cb;
+    P.N = N; P.Z = Z; P.S = S;
+    P.out_h = h[i].p; P.out_h_nstride = ns;
+    e = launch_prep(P, st);
+  }
+  TVH o = h[0];
+  o.p = (uint16_t*)out;
+  if (e == hipSuccess) e = launch_window_attn_bf16(h[0], h[1], h[2], (const float*)qw_dev, (const float*)kw_dev, o, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "window attention launch: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "window attention execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
 extern "C" int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, void* y, int N, int Cin,

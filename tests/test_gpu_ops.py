@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import util
+from teramind_amd import _lib
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -154,3 +155,50 @@ def test_conv1_bf16_exact_integers(N, Cin, Cout, Z, S):
     ref = F.conv3d(x, w, b)
     got, _ = util.conv1_bf16(x.to(DEV), w, b)
     assert torch.equal(got.cpu(), ref), util.report("conv1 bf16", got, ref)
+
+
+# ---- windowed cross-attention core -------------------------------------------------------------------
+def _window_attn_ref(q, k, v, qw, kw):
+    """fp32 reference of model/MBAblocks.py:560-590 on NCDHW tensors (one head of width C, 2 x 2 windows)."""
+    N, Cc, Z, S, _ = q.shape
+    hs = S // 2
+
+    def win(t):          # [N, C, Z, S, S] -> [N, 4, Z*hs*hs, C]
+        t = t.reshape(N, Cc, Z, 2, hs, 2, hs).permute(0, 3, 5, 2, 4, 6, 1)
+        return t.reshape(N, 4, Z * hs * hs, Cc)
+
+    def rms(t, w):
+        return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+
+    qn, kn, vv = rms(win(q), qw), rms(win(k), kw), win(v)
+    o = torch.softmax((qn / Cc) @ kn.transpose(-2, -1), -1) @ vv
+    o = o.reshape(N, 2, 2, Z, hs, hs, Cc).permute(0, 6, 3, 1, 4, 2, 5)
+    return o.reshape(N, Cc, Z, S, S)
+
+
+@pytest.mark.parametrize("C_,S,dtype", [(256, 16, "f32"), (512, 8, "f32"), (256, 16, "bf16"), (512, 8, "bf16"),
+                                        (128, 16, "bf16")])
+def test_window_attention_core(C_, S, dtype):
+    N, Z = 5, 2
+    g = torch.Generator().manual_seed(C_ + S)
+    q, k, v = (torch.randn((N, C_, Z, S, S), generator=g) * s for s in (1.5, 0.7, 1.0))
+    qw, kw = torch.rand(C_, generator=g) + 0.5, torch.rand(C_, generator=g) + 0.5
+    k = k * 3 + q * 0.5                                   # structured logits: the softmax is far from uniform
+    if dtype == "bf16":
+        q, k, v = (t.bfloat16().float() for t in (q, k, v))
+    ref = _window_attn_ref(q, k, v, qw, kw)
+    qc, kc, vc = (util.to_cb8(t.to(DEV)) for t in (q, k, v))
+    qwd, kwd = qw.to(DEV), kw.to(DEV)
+    if dtype == "f32":
+        out = torch.zeros_like(qc)
+    else:
+        out = torch.zeros(qc.shape, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().tm_op_window_attn(_lib.ptr(qc), _lib.ptr(kc), _lib.ptr(vc), _lib.ptr(qwd), _lib.ptr(kwd), _lib.ptr(out),
+                                            N, C_, Z, S, 0 if dtype == "f32" else 1, _lib.current_stream_ptr()), "tm_op_window_attn")
+    got = util.from_cb8(out.float(), C_).cpu()
+    err = (got - ref).abs().max().item()
+    # bf16: operands q*w, k, P, V rounded to 8 significant bits, fp32 accumulation and softmax
+    tol = 2e-5 if dtype == "f32" else 3e-2
+    assert err < tol, (err, util.report("window_attn", got, ref))
+    if dtype == "bf16":
+        assert ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 1e-2
