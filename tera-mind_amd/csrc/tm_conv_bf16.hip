@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   const int S = a.S;
   const int tiles_c = S / TW, tiles_r = S / G::TR;
   const int tiles = tiles_c * tiles_r;
-  const int bid = blockIdx.x;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;                        // n-tile of TN couts
   int mt_ = bid / a.ntile;
   const int pg = mt_ / (2 * tiles);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* z
   const int lane = tid & 63, wv = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
   const int wn = wv % G::WNW, wm = wv / G::WNW;
-  const int bid = blockIdx.x;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;
   const int mtile = bid / a.ntile;
   const long VPN = (long)a.Z * a.S * a.S, vtot = VPN * a.N;

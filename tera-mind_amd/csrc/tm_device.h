@@ -56,6 +56,14 @@ struct ConvArgs {
   long gate_h_nstride = 0;
 };
 
+// XCD-aware workgroup id (cdna guide T1): the dispatcher deals consecutive blockIdx round-robin over the 8 XCDs
+// (private L2 each); this bijective remap hands every XCD one CONTIGUOUS run of logical tile ids, so the
+// workgroups that share an activation tile (its other cout tiles), a halo or a weight slab hit the same L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 // acc[ct][mt]: cout tile ct (32 couts) x voxel tile mt; cob0 = first 8-cout block of acc[0]
 template <int WM, int WN = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WN][WM], int nt, int h,

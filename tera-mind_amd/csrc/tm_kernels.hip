@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
   const int S = a.S;
   const int tiles_c = S / TW, tiles_r = S / G::TR;
   const int tiles = tiles_c * tiles_r;
-  const int bid = blockIdx.x;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;
   int mt_ = bid / a.ntile;
   const int pg = mt_ / (a.Z * tiles);                            // a.Z = OUTPUT planes
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
-  const int bid = blockIdx.x;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;
   const int mtile = bid / a.ntile;
   const long VPN = (long)a.Z * a.S * a.S;      // voxels per n
