@@ -766,18 +766,21 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   const float* xb = a.x + (long)n * a.x_nstride;
+  // channel block outermost: the 9 taps of one block touch 3 rows of one plane back to back (L1 hits); with the
+  // taps outermost every tap strides through all Cb planes and the rows are evicted before the next tap returns
+  // to them (measured: 8.7x the input bytes fetched from HBM)
+  for (int cb = 0; cb < a.Cb; ++cb) {
+    const float* xc = xb + (long)cb * vpn * 8;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
+    for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int yi = y + ky - 1, xi = x + kx - 1;
-      if (yi < 0 || yi >= S || xi < 0 || xi >= S) continue;
-      const float* xp = xb + ((long)(z * S + yi) * S + xi) * 8;
-      const float* wt = a.w + (long)(ky * 3 + kx) * a.Cb * 64;
-      for (int cb = 0; cb < a.Cb; ++cb) {
-        const f32x4 a0 = *(const f32x4*)(xp + (long)cb * vpn * 8), a1 = *(const f32x4*)(xp + (long)cb * vpn * 8 + 4);
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yi = y + ky - 1, xi = x + kx - 1;
+        if (yi < 0 || yi >= S || xi < 0 || xi >= S) continue;
+        const float* xp = xc + ((long)(z * S + yi) * S + xi) * 8;
+        const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 4);
         const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        const float* wp = wt + cb * 64;
+        const float* wp = a.w + ((long)(ky * 3 + kx) * a.Cb + cb) * 64;
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
