@@ -19,6 +19,7 @@
 // Same operand orientation (weight = A, activation = B) and epilogue as conv3d_mfma.
 #include "tm_device.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace tmk {
@@ -283,22 +284,27 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
 // LDS-DMA instruction is issued unconditionally -- pieces that do not exist (voxels past the end, channel
 // pairs past Cbp, ring slots past the last stage) read a zero page -- so each wave issues exactly LPS
 // instructions per stage and the vmcnt immediate is a compile-time constant.
-template <int TN>
+// NWV = waves per workgroup: 8 (one 128 x 512 / 64 x 1024 workgroup per CU) or 4 (two co-resident 128 x 256 / 64 x 512
+// workgroups per CU: the K loops here are 4..64 stages long, and with a single workgroup per CU nothing covers its ring
+// fill, drain and epilogue; with two, one's tail overlaps the other's MFMAs).
+template <int TN, int NWV>
 struct H1Geo {
-  static constexpr int WNW = TN / 64, WMW = 8 / WNW, TM = WMW * 128;
+  static constexpr int NT = NWV * 64;
+  static constexpr int WNW = TN / 64, WMW = NWV / WNW, TM = WMW * 128;
   static constexpr int KP = TN / 64;                             // channel-block pairs per stage (1 | 2)
   static constexpr int NB = 3;                                   // ring depth
   static constexpr int WPIECES = KP * TN * 2, XPIECES = KP * TM * 2;
-  static constexpr int WSLOTS = 512;                             // weight region padded to one instruction per wave
-  static constexpr int PW = 1, PX = XPIECES / 512, LPS = PW + PX;
+  static constexpr int WSLOTS = (WPIECES + NT - 1) / NT * NT;    // weight region: whole workgroup-instructions
+  static constexpr int PW = WSLOTS / NT, PX = XPIECES / NT, LPS = PW + PX;
   static constexpr int BUF16 = WSLOTS + XPIECES;
   static constexpr int LDS_BYTES = NB * BUF16 * 16;
 };
 
-template <int TN>
-__global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* zero_page) {
-  using G = H1Geo<TN>;
-  static_assert(G::WPIECES <= G::WSLOTS && G::XPIECES % 512 == 0, "staging shape");
+template <int TN, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const void* zero_page) {
+  using G = H1Geo<TN, NWV>;
+  constexpr int NT = G::NT;
+  static_assert(G::WPIECES <= G::WSLOTS && G::XPIECES % NT == 0 && G::WSLOTS % NT == 0, "staging shape");
   const ConvArgs& a = ah.c;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
   const int tid = threadIdx.x;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* z
   int xkp[G::PX];
 #pragma unroll
   for (int k = 0; k < G::PX; ++k) {
-    const int i = tid + k * 512;                       // piece i -> LDS slot WSLOTS + i  ([kp][k-half][voxel])
+    const int i = tid + k * NT;                        // piece i -> LDS slot WSLOTS + i  ([kp][k-half][voxel])
     const int v = i % G::TM;
     const int half = (i / G::TM) & 1;
     xkp[k] = i / (2 * G::TM);
@@ -329,9 +335,8 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* z
     }
     xoff[k] = off;
   }
-  // packed weights: [n-tile][pair][TN][2][8]; this lane's piece tid of a stage belongs to pair tid / (TN*2)
+  // packed weights: [n-tile][pair][TN][2][8]; piece i = tid + k*NT of a stage belongs to pair i / (TN*2)
   const __bf16* wsrc = wg + (long)nt * ah.Cbp * TN * 16 + (long)tid * 8;
-  const int wkp = tid / (TN * 2);
 
   int xb[4], on[4], ooff[4];
 #pragma unroll
@@ -361,17 +366,21 @@ __global__ __launch_bounds__(512, 2) void conv1_bf16(ConvArgsH ah, const void* z
     u32x4* base = lds16 + (st % G::NB) * G::BUF16;
     // the source address is selected arithmetically and laundered through a VGPR: a `cond ? ptr : zp` that
     // hipcc turns into two predicated DMA instructions would break the per-stage instruction count
-    const bool wok = st < NS && tid < G::WPIECES && p0 + wkp < ah.Cbp;
-    unsigned long long wa = wok ? (unsigned long long)(wsrc + (long)p0 * TN * 16) : (unsigned long long)zp;
-    asm volatile("" : "+v"(wa));
-    TM_GLDS16((const void*)wa, base + wv * 64);
+#pragma unroll
+    for (int k = 0; k < G::PW; ++k) {
+      const int i = tid + k * NT;
+      const bool wok = st < NS && i < G::WPIECES && p0 + i / (TN * 2) < ah.Cbp;
+      unsigned long long wa = wok ? (unsigned long long)(wsrc + (long)p0 * TN * 16 + (long)k * NT * 8) : (unsigned long long)zp;
+      asm volatile("" : "+v"(wa));
+      TM_GLDS16((const void*)wa, base + k * NT + wv * 64);
+    }
 #pragma unroll
     for (int k = 0; k < G::PX; ++k) {
       const int pr = p0 + xkp[k];
       const bool ok = st < NS && xoff[k] >= 0 && pr < ah.Cbp;
       unsigned long long xa = ok ? (unsigned long long)(xg + (long)pr * 2 * ah.x_plane_e + xoff[k]) : (unsigned long long)zp;
       asm volatile("" : "+v"(xa));
-      TM_GLDS16((const void*)xa, base + G::WSLOTS + k * 512 + wv * 64);
+      TM_GLDS16((const void*)xa, base + G::WSLOTS + k * NT + wv * 64);
     }
   };
 
@@ -715,6 +724,12 @@ static const void* zero_page(hipError_t* err) {
   return zp;
 }
 
+static bool tm_conv1_small_wg() {        // TM_CONV1_WAVES=8 selects the single 8-wave workgroup per CU (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TM_CONV1_WAVES"); v = (e && atoi(e) == 8) ? 0 : 1; }
+  return v == 1;
+}
+
 hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   hipError_t zerr = hipSuccess;
   const void* zp = zero_page(&zerr);
@@ -737,20 +752,22 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.ntile = (L.Cout + TN - 1) / TN;
   if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
   const long vox = (long)a.N * a.Z * a.S * a.S;
-#define TM_LAUNCH1H(TN_)                                                                         \
+#define TM_LAUNCH1H(TN_, NWV_)                                                                   \
   do {                                                                                          \
-    using G = H1Geo<TN_>;                                                                       \
+    using G = H1Geo<TN_, NWV_>;                                                                 \
     static bool attr_done = false;                                                              \
     if (!attr_done) {                                                                           \
-      hipError_t e = hipFuncSetAttribute((const void*)conv1_bf16<TN_>,                          \
+      hipError_t e = hipFuncSetAttribute((const void*)conv1_bf16<TN_, NWV_>,                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
       attr_done = true;                                                                         \
     }                                                                                           \
     const long grid = ((vox + G::TM - 1) / G::TM) * a.ntile;                                    \
-    hipLaunchKernelGGL((conv1_bf16<TN_>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah, zp); \
+    hipLaunchKernelGGL((conv1_bf16<TN_, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah, zp); \
   } while (0)
-  if (TN == 64) TM_LAUNCH1H(64); else TM_LAUNCH1H(128);
+  const bool small_wg = tm_conv1_small_wg();
+  if (TN == 64) { if (small_wg) TM_LAUNCH1H(64, 4); else TM_LAUNCH1H(64, 8); }
+  else { if (small_wg) TM_LAUNCH1H(128, 4); else TM_LAUNCH1H(128, 8); }
 #undef TM_LAUNCH1H
   return hipGetLastError();
 }
