@@ -35,12 +35,24 @@ class TileSweep:
     def __init__(self, conf: PathConfig, sampler, model, gene_provider: Callable[[int, int], torch.Tensor],
                  hst: int = 256, wst: int = 256, hnm: int = 32, wnm: int = 32, total_epochs: int = 15,
                  total_slc: int = 50, device="cpu", rank: int = 0, world: int = 1, batch_tiles: int = 1,
-                 group=None, init: str = "reference", noise_provider: Optional[Callable] = None):
+                 group=None, init: str = "reference", noise_provider: Optional[Callable] = None,
+                 state: str = "fp32x2"):
         """hst/wst/hnm/wnm/total_epochs mirror the test_brn CLI (test_brn.py:302-334).
         gene_provider(row, col) -> dense [20, 20, (total_slc + 2*zpad) * 500] gene tile (already
         block-summed and z-padded like MBADataset_tst._getgene/_pad_gn) for ABSOLUTE tile
         (row, col).  init: 'reference' = LCG-seeded CPU randn per tile; 'device' = torch.randn
-        on the device seeded per tile (fast, not the reference's stream)."""
+        on the device seeded per tile (fast, not the reference's stream).
+        state: 'fp32x2' = two fp32 canvases (read / write), 8 B per state element;
+               'fp16'   = ONE float16 canvas, 2 B per element -- the layout that holds the whole brain
+               (118 404 tiles x 256^2 x 100 = 1.55 TB) in the 8 x 288 GB of one node (SURVEY.md 8e capacity
+               note).  Every value the reference keeps between steps is float16 (test_brn.py:222), so the
+               canvas is lossless from step 1 on; step 0's float32 noise is never stored -- a three-row band of
+               noise tiles is regenerated from the LCG seeds as the sweep moves down -- and new tile rows are
+               committed one row late, once the row below has consumed the old halo.  Results are
+               bit-identical to 'fp32x2'."""
+        if state not in ("fp32x2", "fp16"):
+            raise ValueError(f"state {state!r}")
+        self.state = state
         if conf.rna_slc not in (4, 8, 16):
             raise NotImplementedError("TileSweep implements the z-chunked configs (rna_slc in 4, 8, 16)")
         self.conf, self.sampler, self.model, self.gene = conf, sampler, model, gene_provider
@@ -54,10 +66,15 @@ class TileSweep:
         self.nrows = self.r1 - self.r0
         H = self.nrows * tiles.TILE + 2 * PAD
         W = wnm * tiles.TILE + 2 * PAD
+        self.epoch = 0
+        self._pending, self._noise_rows, self._strips = {}, {}, {}
+        if state == "fp16":
+            self.cur = torch.full((self.chn, H, W), -1.0, dtype=torch.float16, device=self.dev)
+            self.nxt = None
+            return
         # two canvases (read: step e, write: step e+1); frame initialised to -1
         self.cur = torch.full((self.chn, H, W), -1.0, dtype=torch.float32, device=self.dev)
         self.nxt = torch.full((self.chn, H, W), -1.0, dtype=torch.float32, device=self.dev)
-        self.epoch = 0
         self._fill_initial_noise()
         self._exchange(self.cur)
 
@@ -66,17 +83,56 @@ class TileSweep:
         y, x = PAD + lr * tiles.TILE, PAD + c * tiles.TILE
         return canvas[:, y:y + tiles.TILE, x:x + tiles.TILE]
 
+    def _noise_tile(self, row: int, col: int) -> torch.Tensor:
+        """Step-0 tile 'h w c' at ABSOLUTE grid position (utils/MBADataset_tst.py:49-58)."""
+        if self.init == "reference":
+            return tiles.initial_noise_tile(row, col, self.chn)
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(tiles.tile_noise_seed(row, col))
+        return torch.randn((tiles.TILE, tiles.TILE, self.chn), generator=g, device=self.dev)
+
     def _fill_initial_noise(self):
         for lr in range(self.nrows):
             for c in range(self.wnm):
-                row, col = self.row0 + self.r0 + lr, self.col0 + c
-                if self.init == "reference":
-                    t = tiles.initial_noise_tile(row, col, self.chn)
-                else:
-                    g = torch.Generator(device=self.dev)
-                    g.manual_seed(tiles.tile_noise_seed(row, col))
-                    t = torch.randn((tiles.TILE, tiles.TILE, self.chn), generator=g, device=self.dev)
+                t = self._noise_tile(self.row0 + self.r0 + lr, self.col0 + c)
                 self._centre(self.cur, lr, c).copy_(t.permute(2, 0, 1))
+
+    # ---- 'fp16' state: row strips --------------------------------------------------------------
+    def _noise_row(self, lr: int) -> torch.Tensor:
+        """[C, 256, wnm*256] float32 noise of local row lr (may be -1 or nrows: the neighbouring rank's row, or
+        all -1 outside the ROI, MBADataset_tst.py:95-101); a three-row band is kept."""
+        if lr not in self._noise_rows:
+            row = self.r0 + lr                                   # row inside the ROI
+            band = torch.full((self.chn, tiles.TILE, self.wnm * tiles.TILE), -1.0, dtype=torch.float32, device=self.dev)
+            if 0 <= row < self.hnm:
+                for c in range(self.wnm):
+                    t = self._noise_tile(self.row0 + row, self.col0 + c)
+                    band[:, :, c * tiles.TILE:(c + 1) * tiles.TILE].copy_(t.permute(2, 0, 1))
+            self._noise_rows[lr] = band
+            for k in [k for k in self._noise_rows if k < lr - 2]:
+                del self._noise_rows[k]
+        return self._noise_rows[lr]
+
+    def _strip(self, lr: int) -> torch.Tensor:
+        """[C, 256+64, W] float32: local tile row lr with its 32-px halo, as the step reads it."""
+        if lr in self._strips:
+            return self._strips[lr]
+        y = lr * tiles.TILE
+        if self.epoch > 0:
+            st = self.cur[:, y:y + tiles.TILE + 2 * PAD, :].float()
+        else:
+            st = torch.full((self.chn, tiles.TILE + 2 * PAD, self.cur.shape[2]), -1.0, dtype=torch.float32, device=self.dev)
+            st[:, :PAD, PAD:-PAD] = self._noise_row(lr - 1)[:, -PAD:, :]
+            st[:, PAD:-PAD, PAD:-PAD] = self._noise_row(lr)
+            st[:, -PAD:, PAD:-PAD] = self._noise_row(lr + 1)[:, :PAD, :]
+        self._strips = {k: v for k, v in self._strips.items() if k >= lr - 1}
+        self._strips[lr] = st
+        return st
+
+    def _commit_rows(self, upto: int):
+        """Write the pending new rows <= upto into the canvas (their old values have been consumed)."""
+        for lr in sorted(k for k in self._pending if k <= upto):
+            self.cur[:, PAD + lr * tiles.TILE:PAD + (lr + 1) * tiles.TILE, PAD:-PAD].copy_(self._pending.pop(lr))
 
     def _exchange(self, canvas):
         """32-px strips to / from the neighbouring ranks (full canvas width: corners included)."""
@@ -104,6 +160,8 @@ class TileSweep:
     # ---- one diffusion step over the rank's tiles ----------------------------------------------
     def _window(self, lr: int, c: int) -> torch.Tensor:
         y, x = lr * tiles.TILE, c * tiles.TILE
+        if self.state == "fp16":
+            return self._strip(lr)[:, :, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)
         return self.cur[:, y:y + tiles.TILE + 2 * PAD, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)     # 'h w c'
 
     def run_batch(self, tile_list, epoch: int):
@@ -115,6 +173,14 @@ class TileSweep:
         out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
                                   patch_size=conf.patch_size, idx=self.T - epoch - 1, model_kwargs=None)
         out = tiles.regroup_output(out, len(tile_list), self.n_stain)
+        if self.state == "fp16":
+            out = out.half()                                                  # test_brn.py:222
+            for k, (lr, c) in enumerate(tile_list):
+                if lr not in self._pending:
+                    self._pending[lr] = torch.empty((self.chn, tiles.TILE, self.wnm * tiles.TILE), dtype=torch.float16,
+                                                    device=self.dev)
+                self._pending[lr][:, :, c * tiles.TILE:(c + 1) * tiles.TILE].copy_(out[k])
+            return
         out = out.half().float()                                              # test_brn.py:222
         for k, (lr, c) in enumerate(tile_list):
             self._centre(self.nxt, lr, c).copy_(out[k])
@@ -122,7 +188,18 @@ class TileSweep:
     def step(self):
         todo = [(lr, c) for lr in range(self.nrows) for c in range(self.wnm)]
         for i in range(0, len(todo), self.batch_tiles):
-            self.run_batch(todo[i:i + self.batch_tiles], self.epoch)
+            batch = todo[i:i + self.batch_tiles]
+            self.run_batch(batch, self.epoch)
+            if self.state == "fp16":
+                # rows before the last one touched are complete; row q's old values are still read by row q+1
+                done = batch[-1][0] - (0 if batch[-1][1] == self.wnm - 1 else 1)
+                self._commit_rows(done - 1)
+        if self.state == "fp16":
+            self._commit_rows(self.nrows)
+            self._strips, self._noise_rows = {}, {}
+            self._exchange(self.cur)
+            self.epoch += 1
+            return
         self._exchange(self.nxt)
         self.cur, self.nxt = self.nxt, self.cur
         self.epoch += 1
@@ -175,6 +252,7 @@ class TileSweep:
             raise ValueError(f"epoch {epoch} outside 1..{self.T}")
         d = self.step_dir(out_dir, epoch)
         self.cur.fill_(-1.0)
+        self._pending, self._strips, self._noise_rows = {}, {}, {}
         for lr in range(self.nrows):
             for c in range(self.wnm):
                 name = tiles.state_tile_name(self.row0 + self.r0 + lr, self.col0 + c)

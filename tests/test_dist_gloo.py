@@ -43,18 +43,19 @@ def gene_provider(row, col):
     return (torch.rand((20, 20, (SLC + 2) * 500), generator=g) < 0.01).float()
 
 
-def make_sweep(rank, world):
+def make_sweep(rank, world, state="fp32x2", batch_tiles=2):
     return TileSweep(PathConfig(), StandInSampler(), None, gene_provider, hst=512, wst=768, hnm=HNM, wnm=WNM,
-                     total_epochs=T, total_slc=SLC, device="cpu", rank=rank, world=world, batch_tiles=2)
+                     total_epochs=T, total_slc=SLC, device="cpu", rank=rank, world=world, batch_tiles=batch_tiles,
+                     state=state)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, state="fp32x2"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sw = make_sweep(rank, world)
-        out = sw.test().clone()
+        sw = make_sweep(rank, world, state)
+        out = sw.test().float().clone()
         q.put((rank, sw.r0, sw.r1, out.numpy()))     # by value: the worker may exit before the parent reads
         dist.barrier()
     finally:
@@ -69,8 +70,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_sweep_equals_single_rank(world):
+@pytest.mark.parametrize("world,state", [(2, "fp32x2"), (3, "fp32x2"), (2, "fp16")])
+def test_row_sharded_sweep_equals_single_rank(world, state):
     torch.set_num_threads(4)
     ref = make_sweep(0, 1).test()
     assert ref.shape == (SLC * 2, HNM * 256, WNM * 256)
@@ -78,7 +79,7 @@ def test_row_sharded_sweep_equals_single_rank(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, state)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
@@ -88,6 +89,19 @@ def test_row_sharded_sweep_equals_single_rank(world):
     for rank, r0, r1, out in got:
         assert torch.equal(torch.from_numpy(out), ref[:, r0 * 256:r1 * 256, :]), f"rank {rank} rows [{r0},{r1}) differ from the single-rank sweep"
 
+
+
+@pytest.mark.parametrize("batch_tiles", [1, 3, 6])
+def test_single_fp16_canvas_state_is_bit_identical(batch_tiles):
+    """state='fp16' (one float16 canvas, rows committed one row late, step-0 noise regenerated in a band):
+    the whole-brain memory layout gives exactly the two-canvas result, also with batches that span tile rows."""
+    torch.set_num_threads(4)
+    ref = make_sweep(0, 1).test()
+    sw = make_sweep(0, 1, "fp16", batch_tiles)
+    assert sw.nxt is None and sw.cur.dtype == torch.float16
+    got = sw.test()
+    assert got.dtype == torch.float16 and torch.equal(got.float(), ref)
+    assert not sw._pending and not sw._strips
 
 
 def test_halo_dependence_is_real():

@@ -43,3 +43,18 @@ def test_tile_sweep_hip_vs_oracle():
     # after every step so a 1-ulp fp16 flip (1e-3 at |x|~1) is the granularity
     d = (got.cpu() - ref).abs()
     assert d.max() <= 2e-3 and d.mean() <= 2e-5, util.report("sweep", got, ref)
+
+
+def test_tile_sweep_single_fp16_canvas_equals_two_canvas_state():
+    """state='fp16' (the whole-brain memory layout: one float16 canvas, rows committed one row late) on the GPU
+    with the HIP model: bit-identical to the default two-canvas fp32 state."""
+    cfg = PathConfig()
+    sd = util.state_dict(cfg)
+    genes = synthetic_gene_provider(cfg, total_slc=SLC)
+    model = BeatGANsUNetModel(cfg, DEV).load_state_dict(sd)
+    kw = dict(hst=256, wst=512, hnm=2, wnm=2, total_epochs=T, total_slc=SLC, device=DEV, init="device")
+    a = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=1, **kw).test()
+    sw = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, state="fp16", **kw)
+    b = sw.test()
+    assert b.dtype == torch.float16 and sw.nxt is None
+    assert torch.equal(b.float(), a)

@@ -161,11 +161,12 @@ class _ToySampler:
         return 0.5 * x[:, :, h:-h, h:-h] + 0.01 * (idx + 1) + g
 
 
-def test_sweep_save_and_resume_from_step_dir(tmp_path):
+@pytest.mark.parametrize("state", ["fp32x2", "fp16"])
+def test_sweep_save_and_resume_from_step_dir(tmp_path, state):
     cfg = PathConfig()
     slc, T = 4, 3
     genes = lambda r, c: torch.full((20, 20, (slc + 2) * 500), float(r + c) * 1e-3)
-    kw = dict(hst=512, wst=256, hnm=2, wnm=2, total_epochs=T, total_slc=slc)
+    kw = dict(hst=512, wst=256, hnm=2, wnm=2, total_epochs=T, total_slc=slc, state=state)
     a = TileSweep(cfg, _ToySampler(), None, genes, **kw)
     a.step()
     a.step()
