@@ -194,12 +194,23 @@ def gene_attention_tokens(W, rna_h: Tensor, want_map: bool = False):
     return o, (prob if want_map else None)
 
 
+# the 81 genes shared with the human-brain panel, as slots of the 500-gene axis (utils/__init__.py:49-57)
+M2H = (1, 4, 5, 11, 21, 22, 23, 24, 25, 27, 35, 38, 40, 55, 56, 57, 61, 67, 69, 70, 75, 84, 90, 91, 96, 108, 111, 113, 118,
+       130, 134, 137, 139, 145, 152, 155, 158, 165, 170, 171, 179, 180, 189, 191, 206, 215, 223, 229, 230, 235, 241, 243,
+       253, 288, 297, 301, 309, 329, 337, 344, 346, 370, 372, 378, 380, 395, 410, 436, 441, 442, 443, 458, 465, 467, 472,
+       478, 487, 492, 493, 494, 496)
+
+
 def dense_rna_to_genes(rna: Tensor, rna_num: int) -> Tensor:
-    """'b h w (z g) -> b g z h w' with g=500, then keep the first rna_num genes.
-    model/unet_ours.py:307-318 (mouse path, not the 81-gene M2H remap)."""
+    """'b h w (z g) -> b g z h w' with g=500, then the model's genes: the first rna_num slots, or -- for the
+    81-gene human-brain generalisation model -- the M2H slots.  model/unet_ours.py:307-318."""
     B, gh, gw, zg = rna.shape
     zs = zg // 500
-    return rna.reshape(B, gh, gw, zs, 500).permute(0, 4, 3, 1, 2)[:, :rna_num].contiguous()
+    rna_h = rna.reshape(B, gh, gw, zs, 500).permute(0, 4, 3, 1, 2)
+    if rna_num == len(M2H):
+        assert zs == 1                                            # unet_ours.py:316
+        return rna_h[:, list(M2H)].contiguous()
+    return rna_h[:, :rna_num].contiguous()
 
 
 def rna_pyramid(W, cfg: OracleConfig, rna: Tensor) -> List[Tensor]:

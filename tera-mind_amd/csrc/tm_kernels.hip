@@ -21,7 +21,9 @@ namespace tmk {
 // NZI selects the z structure of the k x 3 x 3 kernel:
 //   NZI = 2  3x3x3, pad (1,1,1), Z == 2: the z-skip form above (18 of 27 taps per output plane)
 //   NZI = 1  1x3x3, pad (0,1,1): in-plane conv, any Z   (RNA pyramid, model/unet_ours.py:290-295)
-//   NZI = 3  3x3x3, pad (0,1,1): valid in z, Zin = Zout + 2 (down_z, model/MBAblocks.py:472-474)
+//   NZI = 3  3x3x3 over three staged planes zo + zi + zoff: zoff = 0 is valid-in-z (Zin = Zout + 2: down_z,
+//            model/MBAblocks.py:472-474), zoff = -1 with planes outside [0, Zin) zero is pad (1,1,1) for any Z
+//            (the ResBlock convs of the z_size 4 / 8 configs, rna_slc 8 / 16)
 template <int NZI, int WM, int TW>
 struct C3Geo {
   static constexpr int MV = 4 * WM * 32;                         // voxels per workgroup
@@ -75,10 +77,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
       const int hr = v % G::HR; v /= G::HR;
       const int zi = v % NZI;
       const int ps = v / NZI;
-      const int zs = (NZI == 2) ? zi : zo + zi;                  // source plane
+      const int zs = (NZI == 2) ? zi : zo + zi + a.zoff;         // source plane
       const int n = pg * G::NPB + ps;
       const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
-      if (n < a.N && y >= 0 && y < S && x >= 0 && x < S)
+      if (n < a.N && y >= 0 && y < S && x >= 0 && x < S && (NZI == 2 || (zs >= 0 && zs < a.Zin)))
         off = (long)n * a.x_nstride + ((long)(zs * S + y) * S + x) * 8 + half * 4;
     }
     xoff[k] = off;
@@ -350,9 +352,14 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
   // ---- k x 3 x 3 kernels ----
   const int S = a.S;
   int nzi;
-  if (L.zmode == ZM_PAD1) {            // 3x3x3 pad 1, Z == 2
-    if (L.w.taps != 27 || L.x.Z != 2 || L.y.Z != 2) return hipErrorInvalidValue;
-    nzi = 2;
+  a.Zin = L.x.Z; a.zoff = 0;
+  if (L.zmode == ZM_PAD1 && L.w.taps == 9) {   // 3x3x3 pad 1 on ONE plane: only the centre z slice meets data (packed as 9 taps)
+    if (L.x.Z != 1 || L.y.Z != 1) return hipErrorInvalidValue;
+    nzi = 1;
+  } else if (L.zmode == ZM_PAD1) {             // 3x3x3 pad 1
+    if (L.w.taps != 27 || L.y.Z != L.x.Z) return hipErrorInvalidValue;
+    if (L.x.Z == 2) nzi = 2;                   // z-skip form
+    else { nzi = 3; a.zoff = -1; }
   } else if (L.zmode == ZM_INPLANE) {  // 1x3x3
     if (L.w.taps != 9 || L.y.Z != L.x.Z) return hipErrorInvalidValue;
     nzi = 1;
@@ -361,7 +368,7 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
     nzi = 3;
   } else return hipErrorInvalidValue;
   a.Z = L.y.Z;
-  if (S != 4 && S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
+  if (S != 4 && S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
   if ((L.flags & EPI_UP2) ? (L.y.H != 2 * S) : (L.y.H != S)) return hipErrorInvalidValue;
   const long ovox = (long)a.N * a.Z * a.S * a.S;
   int variant = L.tile_variant ? L.tile_variant : ((ovox / 256) * a.ntile >= 512 ? 2 : 1);
@@ -381,18 +388,18 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
     hipLaunchKernelGGL((conv3d_mfma<NZI, WM, TW>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a); \
   } while (0)
   if (nzi == 2) {
-    if (S < 8) return hipErrorInvalidValue;
-    if (variant == 2) {
+    if (S < 8) { if (S != 4) return hipErrorInvalidValue; TM_LAUNCH3(2, 1, 4); }
+    else if (variant == 2) {
       if (S >= 32) TM_LAUNCH3(2, 2, 32); else if (S == 16) TM_LAUNCH3(2, 2, 16); else TM_LAUNCH3(2, 2, 8);
     } else {
       if (S >= 32) TM_LAUNCH3(2, 1, 32); else if (S == 16) TM_LAUNCH3(2, 1, 16); else TM_LAUNCH3(2, 1, 8);
     }
   } else if (nzi == 1) {
-    if (S < 8) return hipErrorInvalidValue;
-    if (S >= 32) TM_LAUNCH3(1, 2, 32); else if (S == 16) TM_LAUNCH3(1, 2, 16); else TM_LAUNCH3(1, 2, 8);
+    if (S >= 32) TM_LAUNCH3(1, 2, 32); else if (S == 16) TM_LAUNCH3(1, 2, 16); else if (S == 8) TM_LAUNCH3(1, 2, 8);
+    else TM_LAUNCH3(1, 1, 4);
   } else {
-    if (S != 4) return hipErrorInvalidValue;
-    TM_LAUNCH3(3, 1, 4);
+    if (S >= 32) TM_LAUNCH3(3, 2, 32); else if (S == 16) TM_LAUNCH3(3, 2, 16); else if (S == 8) TM_LAUNCH3(3, 2, 8);
+    else TM_LAUNCH3(3, 1, 4);
   }
 #undef TM_LAUNCH3
   return hipGetLastError();
@@ -1323,6 +1330,210 @@ hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, cons
   return hipGetLastError();
 }
 
+
+// ---- generic form of the gene-gene attention block ----------------------------------------------------
+// Any gene count G <= 512 and any hidden size D = gn^2 * rna_slc <= 512 (the other patch_size / rna_slc
+// configurations, the 500-gene mice, the 81-gene M2H subset).  Correctness-first VALU kernel: one workgroup per
+// patch, the per-patch intermediates live in a global scratch slab (L2 resident), every Linear processes RB rows
+// per wave so a weight column is fetched once per RB rows.  Same math as the two kernels above:
+// q = Linear(tok), qn = RMSNorm(q)*w, P = softmax(qn.qn^T / D), o = norm2(proj(Wv (P.tok) + bv)), MLP.
+#define GG_RB 4
+struct GeneGenArgs {
+  GeneArgs g;
+  int D;
+  const int* gidx;          // gene g reads slot gidx[g] of the 500 per slice (null: g)
+  float* ws; long ws_stride;
+};
+
+// out[r][c] = bias[c] + sum_k xs[r*K + k] * W_t[k*Nout + c] for this wave's RB rows, 64 outputs (lane) at a time
+template <typename F>
+__device__ __forceinline__ void gg_linear(const float* xs, int K, const float* __restrict__ W_t, const float* __restrict__ bias,
+                                          int Nout, int lane, F&& emit) {
+  for (int c0 = 0; c0 < Nout; c0 += 64) {
+    const int c = c0 + lane;
+    const bool ok = c < Nout;
+    float acc[GG_RB];
+    const float b = ok ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < GG_RB; ++r) acc[r] = b;
+    for (int k = 0; k < K; ++k) {
+      const float w = ok ? W_t[(long)k * Nout + c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) acc[r] = fmaf(xs[r * K + k], w, acc[r]);
+    }
+    emit(c, ok, acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void gene_attn_generic_kernel(GeneGenArgs ga) {
+  const GeneArgs& a = ga.g;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int G = a.G, D = ga.D, Gp = (G + 63) / 64 * 64, Gb = (G + 7) / 8;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = blockIdx.x;
+  const int gg = a.gn * a.gn;
+  float* tok = ga.ws + (long)n * ga.ws_stride;     // [G][D], later the MLP hidden [G][4D]
+  float* qn = tok + (long)G * 4 * D;                // [G][D]
+  float* qnT = qn + (long)G * D;                    // [D][Gp]
+  float* pt = qnT + (long)D * Gp;                   // [G][D]  P.tok, then norm2 output
+  float* xs = sm + wv * (GG_RB * 4 * D + Gp);       // per wave: RB rows x up to 4D inputs, then Gp softmax row
+  float* pr = xs + GG_RB * 4 * D;
+  const long rbase = (long)n * gg * a.zs * 500;
+  for (int i = tid; i < G * D; i += 256) {
+    const int g = i / D, d = i - g * D;
+    const int z = d / gg, hw = d - z * gg;
+    float v = 0.f;
+    if (z >= a.zlo && z < a.zhi) v = a.rna[rbase + ((long)hw * a.zs + z) * 500 + (ga.gidx ? ga.gidx[g] : g)];
+    tok[i] = v;
+  }
+  for (int i = tid; i < D * (Gp - G); i += 256) {   // padded key columns of qnT
+    const int d = i / (Gp - G), u = G + i - d * (Gp - G);
+    qnT[(long)d * Gp + u] = 0.f;
+  }
+  __syncthreads();
+  const float inv_d = 1.0f / (float)D;
+  // ---- q = Linear(tok); qn = RMSNorm(q) * w ----
+  for (int g0 = wv * GG_RB; g0 < G; g0 += 4 * GG_RB) {
+    for (int i = lane; i < GG_RB * D; i += 64) { const int r = i / D; xs[i] = (g0 + r < G) ? tok[(long)(g0 + r) * D + i - r * D] : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    float ss[GG_RB] = {0.f, 0.f, 0.f, 0.f};
+    gg_linear(xs, D, a.w.wq_t, a.w.bq, D, lane, [&](int c, bool ok, const float (&acc)[GG_RB]) {
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) {
+        if (ok && g0 + r < G) qn[(long)(g0 + r) * D + c] = acc[r];
+        ss[r] += ok ? acc[r] * acc[r] : 0.f;
+      }
+    });
+#pragma unroll
+    for (int r = 0; r < GG_RB; ++r) ss[r] = 1.0f / sqrtf(wave_sum(ss[r]) * inv_d + TM_EPS);
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < D; c += 64) {
+      const float w = a.w.qnorm[c];
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r)
+        if (g0 + r < G) {
+          const float v = w * (qn[(long)(g0 + r) * D + c] * ss[r]);
+          qn[(long)(g0 + r) * D + c] = v;
+          qnT[(long)c * Gp + g0 + r] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // ---- P = softmax(qn.qn^T / D) row by row; pt = P.tok ----
+  const int NJ = Gp / 64;                             // <= 8 key chunks per lane
+  for (int g = wv; g < G; g += 4) {
+    for (int i = lane; i < D; i += 64) xs[i] = qn[(long)g * D + i];
+    __builtin_amdgcn_wave_barrier();
+    float lg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lg[j] = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float qv = xs[d];
+      const float* kr = qnT + (long)d * Gp + lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) lg[j] = fmaf(qv, kr[64 * j], lg[j]);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NJ) { lg[j] *= inv_d; if (lane + 64 * j < G) m = fmaxf(m, lg[j]); }      // (q*scale).(k)*scale, scale = D^-1/2
+    m = wave_max(m);
+    float ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NJ) { lg[j] = (lane + 64 * j < G) ? expf(lg[j] - m) : 0.f; ssum += lg[j]; }
+    ssum = wave_sum(ssum);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NJ) {
+        const int u = lane + 64 * j;
+        const float p = lg[j] / ssum;
+        pr[u] = p;
+        if (a.attn_map && u < G) a.attn_map[((long)n * G + g) * G + u] = p;
+      }
+    __builtin_amdgcn_wave_barrier();
+    if (a.out_tok) {
+      for (int c = lane; c < D; c += 64) {
+        float acc = 0.f;
+        for (int u = 0; u < G; ++u) acc = fmaf(pr[u], tok[(long)u * D + c], acc);
+        pt[(long)g * D + c] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!a.out_tok) return;
+  __syncthreads();
+  // ---- ov = Wv.pt + bv; op = Wp.ov + bp; norm2; MLP ----
+  float* hrow = tok;                                  // [G][4D] MLP hidden: tok is dead (every wave is past the P.tok pass)
+  for (int g0 = wv * GG_RB; g0 < G; g0 += 4 * GG_RB) {
+    float* x0 = xs;                                   // [RB][D]
+    float* x1 = xs + GG_RB * D;                       // [RB][D]
+    for (int i = lane; i < GG_RB * D; i += 64) { const int r = i / D; x0[i] = (g0 + r < G) ? pt[(long)(g0 + r) * D + i - r * D] : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    gg_linear(x0, D, a.w.wv_t, a.w.bv, D, lane, [&](int c, bool ok, const float (&acc)[GG_RB]) {
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) if (ok) x1[r * D + c] = acc[r];
+    });
+    __builtin_amdgcn_wave_barrier();
+    float ss[GG_RB] = {0.f, 0.f, 0.f, 0.f};
+    gg_linear(x1, D, a.w.wp_t, a.w.bp, D, lane, [&](int c, bool ok, const float (&acc)[GG_RB]) {
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) { if (ok) x0[r * D + c] = acc[r]; ss[r] += ok ? acc[r] * acc[r] : 0.f; }
+    });
+#pragma unroll
+    for (int r = 0; r < GG_RB; ++r) ss[r] = 1.0f / sqrtf(wave_sum(ss[r]) * inv_d + TM_EPS);
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < D; c += 64) {              // norm2 (x1 <- normalised rows)
+      const float w = a.w.norm2[c];
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) x1[r * D + c] = w * (x0[r * D + c] * ss[r]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    gg_linear(x1, D, a.w.w1_t, a.w.b1, 4 * D, lane, [&](int c, bool ok, const float (&acc)[GG_RB]) {
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) if (ok && g0 + r < G) hrow[(long)(g0 + r) * 4 * D + c] = gelu_tanh_f(acc[r]);
+    });
+    __threadfence_block();                            // the hidden rows are re-read by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < GG_RB * 4 * D; i += 64) { const int r = i / (4 * D); xs[i] = (g0 + r < G) ? hrow[(long)(g0 + r) * 4 * D + i - r * 4 * D] : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    gg_linear(xs, 4 * D, a.w.w2_t, a.w.b2, D, lane, [&](int c, bool ok, const float (&acc)[GG_RB]) {
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r)
+        if (ok && g0 + r < G) a.out_tok[(((long)n * Gb + ((g0 + r) >> 3)) * D + c) * 8 + ((g0 + r) & 7)] = acc[r];
+    });
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+size_t gene_generic_ws_floats(int G, int D) {
+  const size_t Gp = (size_t)(G + 63) / 64 * 64;
+  // tok [G][D] (reused as the MLP hidden [G][4D]) + qn [G][D] + qnT [D][Gp] + pt [G][D]
+  return (size_t)G * 4 * D + (size_t)G * D + (size_t)D * Gp + (size_t)G * D;
+}
+
+hipError_t launch_gene_attn_generic(const float* rna, int B, int gn, int zs, int G, int D, const GeneW& w, const int* gidx,
+                                    float* out_tok, float* attn_map, int zlo, int zhi, float* ws, hipStream_t s) {
+  if (G < 1 || G > 512 || D < 1 || D > 512 || gn * gn * zs != D) return hipErrorInvalidValue;
+  GeneGenArgs ga;
+  ga.g.rna = rna; ga.g.B = B; ga.g.gn = gn; ga.g.zs = zs; ga.g.G = G; ga.g.w = w;
+  ga.g.out_tok = out_tok; ga.g.attn_map = attn_map; ga.g.scratch = nullptr; ga.g.zlo = zlo; ga.g.zhi = zhi;
+  ga.D = D; ga.gidx = gidx; ga.ws = ws; ga.ws_stride = (long)gene_generic_ws_floats(G, D);
+  const int Gp = (G + 63) / 64 * 64;
+  const size_t lds = (size_t)4 * (GG_RB * 4 * D + Gp) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gene_attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gene_attn_generic_kernel, dim3(B), dim3(256), lds, s, ga);
+  return hipGetLastError();
+}
+
 // rna_h[:, :, 1:-1] of the attention-map model (model/unet_attn.py:173): [B][G][zs-2][gn][gn]
 __global__ void rna_mid_kernel(const float* rna, int B, int gn, int zs, int G, float* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1660,6 +1871,99 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
   }
 }
 
+
+// ---- generic windowed attention core: any window size T = Z*(S/2)^2 <= 512, C <= 512 (fp32, VALU) ------------------
+// The other patch_size / rna_slc configurations (T = 8 ... 512).  One workgroup per (patch, window), one query per wave at
+// a time: lanes = keys for the logits, lanes = channel blocks for P.V.  < 0.5 % of the FLOPs; correctness first.
+__global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int T) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = a.C, Cb = C / 8;
+  int* tokoff = (int*)sm;                  // [T]
+  float* rq = sm + T;                      // [T]
+  float* rk = rq + T;                      // [T]
+  float* w2 = rk + T;                      // [C]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* qrow = w2 + C + wv * (C + T);     // [C]
+  float* prow = qrow + C;                  // [T]
+  const int n = blockIdx.x >> 2, win = blockIdx.x & 3;
+  const int wy = win >> 1, wx = win & 1;
+  const int S = a.S, hs = S / 2;
+  for (int t = tid; t < T; t += 256) {
+    const int z = t / (hs * hs);
+    const int r = t - z * hs * hs;
+    const int yl = r / hs, xl = r - yl * hs;
+    tokoff[t] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
+  __syncthreads();
+  const float* qb = a.q + (long)n * a.q_ns;
+  const float* kb = a.k + (long)n * a.k_ns;
+  const float* vb = a.v + (long)n * a.v_ns;
+  for (int i = tid; i < 2 * T; i += 256) {
+    const bool isq = i < T;
+    const int t = isq ? i : i - T;
+    const float* p = (isq ? qb : kb) + tokoff[t];
+    float ss = 0.f;
+    for (int cb = 0; cb < Cb; ++cb) {
+      const f32x4 a0 = *(const f32x4*)(p + (long)cb * a.plane), a1 = *(const f32x4*)(p + (long)cb * a.plane + 4);
+      ss += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] + a1[0] * a1[0] + a1[1] * a1[1] +
+            a1[2] * a1[2] + a1[3] * a1[3];
+    }
+    const float r = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+    if (isq) rq[t] = r; else rk[t] = r;
+  }
+  __syncthreads();
+  const int NJ = (T + 63) / 64;            // <= 8 key chunks per lane
+  for (int t = wv; t < T; t += 4) {
+    const float sq = rq[t] / (float)C;     // (q*scale).(k*scale), scale = C^-1/2 (MBAblocks.py:571-577)
+    for (int c = lane; c < C; c += 64) qrow[c] = qb[tokoff[t] + (long)(c >> 3) * a.plane + (c & 7)] * w2[c] * sq;
+    __builtin_amdgcn_wave_barrier();
+    float lg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      lg[j] = -INFINITY;
+      const int u = lane + 64 * j;
+      if (j < NJ && u < T) {
+        const float* kp = kb + tokoff[u];
+        float acc = 0.f;
+        for (int cb = 0; cb < Cb; ++cb) {
+          const f32x4 k0 = *(const f32x4*)(kp + (long)cb * a.plane), k1 = *(const f32x4*)(kp + (long)cb * a.plane + 4);
+          const float* qc = qrow + cb * 8;
+          acc += qc[0] * k0[0] + qc[1] * k0[1] + qc[2] * k0[2] + qc[3] * k0[3] + qc[4] * k1[0] + qc[5] * k1[1] +
+                 qc[6] * k1[2] + qc[7] * k1[3];
+        }
+        lg[j] = acc * rk[u];
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, lg[j]);
+    m = wave_max(m);
+    float ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lg[j] = (lg[j] == -INFINITY) ? 0.f : expf(lg[j] - m); ssum += lg[j]; }
+    ssum = wave_sum(ssum);
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int u = lane + 64 * j; if (j < NJ && u < T) prow[u] = lg[j] * inv; }
+    __builtin_amdgcn_wave_barrier();
+    for (int cb = lane; cb < Cb; cb += 64) {
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* vp = vb + (long)cb * a.plane;
+      for (int u = 0; u < T; ++u) {
+        const float p = prow[u];
+        const f32x4 v0 = *(const f32x4*)(vp + tokoff[u]), v1 = *(const f32x4*)(vp + tokoff[u] + 4);
+        o[0] = fmaf(p, v0[0], o[0]); o[1] = fmaf(p, v0[1], o[1]); o[2] = fmaf(p, v0[2], o[2]); o[3] = fmaf(p, v0[3], o[3]);
+        o[4] = fmaf(p, v1[0], o[4]); o[5] = fmaf(p, v1[1], o[5]); o[6] = fmaf(p, v1[2], o[6]); o[7] = fmaf(p, v1[3], o[7]);
+      }
+      float* op = a.o + (long)n * a.o_ns + tokoff[t] + (long)cb * a.plane;
+      *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
+      *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int T>
 static hipError_t launch_win(const WinArgs& a, int N, hipStream_t s) {
   const size_t lds = ((size_t)3 * T + 2 * 16 * T + (size_t)T * (T + 4) + 16 * 128) * sizeof(float);
@@ -1680,8 +1984,14 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
   a.q = q.p; a.k = k.p; a.v = v.p; a.q_ns = q.nstride; a.k_ns = k.nstride; a.v_ns = v.nstride;
   a.qw = qnorm_w; a.kw = knorm_w; a.o = o.p; a.o_ns = o.nstride;
   a.C = q.Cb * 8; a.Z = q.Z; a.S = q.H; a.plane = q.plane();
-  if (a.C % 128 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
+  if (a.C % 8 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
+  if ((T != 128 && T != 32) || a.C % 128) {            // the other configurations: generic kernel (fp32 output only)
+    if (T > 512 || a.C > 512 || o_h) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)3 * T + a.C + 4 * (a.C + T)) * sizeof(float);
+    hipLaunchKernelGGL(window_attn_generic_kernel, dim3(q.N * 4), dim3(256), lds, s, a, T);
+    return hipGetLastError();
+  }
   if (T == 128 && a.C <= 512) {
     static bool attr_set = false;
     const size_t lds = (size_t)WinLds::FLOATS * sizeof(float);

@@ -94,7 +94,10 @@ struct tm_model {
   const float *emb_w = nullptr, *emb_b = nullptr;
   GeneW gene;
   ConvW downz, pyr[3];
-  DirectW stem, head;
+  DirectW stem, head, downz_d;       // downz_d: direct-conv form of down_z when the MFMA form does not apply
+  bool downz_mfma = true;            // kz == 3 on a 4 x 4 gene grid (the checkpoint config)
+  bool gene_mfma = true;             // D == 64, G <= 232, no gene index table: fused MFMA gene-attention kernel
+  const int* gene_idx = nullptr;     // device table: gene g reads slot gene_idx[g] (81-gene M2H subset) or null
   const float* out_norm = nullptr;
   // measurement hooks (tm_profile_*)
   bool prof_on = false;
@@ -285,11 +288,19 @@ extern "C" const char* tm_last_error(void) { return g_err; }
 extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
   if (!cfg || !out) return fail(TM_ERR_ARG, "null argument");
   if (cfg->dtype != TM_DTYPE_F32 && cfg->dtype != TM_DTYPE_BF16) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_F32 or TM_DTYPE_BF16");
-  if (cfg->patch_size != 64 || cfg->rna_slc != 4)
-    return fail(TM_ERR_ARG, "only patch_size=64, rna_slc=4 (checkpoint config) is implemented, got %d/%d",
-                cfg->patch_size, cfg->rna_slc);
-  if (cfg->n_stain < 1 || cfg->n_stain > 2 || cfg->rna_num < 1 || cfg->rna_num > 256)
+  if (cfg->patch_size != 32 && cfg->patch_size != 64 && cfg->patch_size != 128)
+    return fail(TM_ERR_ARG, "patch_size must be 32, 64 or 128 (config_parm.py:47-55), got %d", cfg->patch_size);
+  if (cfg->rna_slc != 1 && cfg->rna_slc != 4 && cfg->rna_slc != 8 && cfg->rna_slc != 16)
+    return fail(TM_ERR_ARG, "rna_slc must be 1, 4, 8 or 16 (train.py:24-26), got %d", cfg->rna_slc);
+  if (cfg->n_stain < 1 || cfg->n_stain > 2 || cfg->rna_num < 1 || cfg->rna_num > 512)
     return fail(TM_ERR_ARG, "n_stain/rna_num out of range");
+  if ((cfg->patch_size / 16) * (cfg->patch_size / 16) * cfg->rna_slc > 512)
+    return fail(TM_ERR_ARG, "gene-token width gn^2 * rna_slc = %d > 512 is not implemented (patch_size 128 with rna_slc 16)",
+                (cfg->patch_size / 16) * (cfg->patch_size / 16) * cfg->rna_slc);
+  if (cfg->rna_num == 81 && cfg->rna_slc != 1)
+    return fail(TM_ERR_ARG, "the 81-gene human-brain subset requires rna_slc = 1 (model/unet_ours.py:313-316)");
+  if (cfg->dtype == TM_DTYPE_BF16 && (cfg->patch_size != 64 || cfg->rna_slc != 4 || cfg->rna_num > 232))
+    return fail(TM_ERR_ARG, "TM_DTYPE_BF16 is implemented for the checkpoint geometry only (patch_size 64, rna_slc 4, rna_num <= 232)");
   if (cfg->net_ch % 64 || cfg->embed_ch % 64 || cfg->embed_ch > 1024)
     return fail(TM_ERR_ARG, "net_ch must be a multiple of 64, embed_ch a multiple of 64 <= 1024");
   tm_model* m = new tm_model();
@@ -297,6 +308,8 @@ extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
   m->z = (cfg->rna_slc + 1) / 2;
   m->gn = cfg->patch_size / 16;
   m->D = m->gn * m->gn * cfg->rna_slc;
+  m->gene_mfma = m->D == 64 && cfg->rna_num <= 232 && cfg->rna_num != 81;
+  m->downz_mfma = cfg->rna_slc == 4 && m->gn == 4;
   m->rw[0] = cfg->rna_num;
   for (int i = 0; i < 3; ++i) m->rw[i + 1] = RNA_TAIL[i];
   int rc = build_graph(m);
@@ -350,12 +363,23 @@ struct FixH { const uint16_t** slot; size_t off; };   // offsets in floats into 
 static const std::vector<float>& P(tm_model* m, const std::string& k) { return m->host[k].data; }
 
 static void pack_conv(tm_model* m, Packer& pk, std::vector<Fix>& fx, ConvW& cw, const std::string& wkey,
-                      const std::string& bkey, int Cout, const std::vector<int>& seg, int taps) {
-  int cbi = 0;
-  for (int c : seg) cbi += (c + 7) / 8;
+                      const std::string& bkey, int Cout, const std::vector<int>& seg, int taps, bool centre_slice = false) {
+  int cbi = 0, cin = 0;
+  for (int c : seg) { cbi += (c + 7) / 8; cin += c; }
+  // centre_slice: a 3x3x3 pad-1 conv applied to ONE plane (z_size 1, rna_slc 1) only ever multiplies its kz = 1 slice
+  // with data -- pack those 9 taps and run the in-plane kernel
+  std::vector<float> centre;
+  const float* wsrc = P(m, wkey).data();
+  if (centre_slice) {
+    centre.resize((size_t)Cout * cin * 9);
+    for (size_t i = 0; i < (size_t)Cout * cin; ++i)
+      for (int t = 0; t < 9; ++t) centre[i * 9 + t] = wsrc[i * 27 + 9 + t];
+    wsrc = centre.data();
+    taps = 9;
+  }
   cw.Cout = Cout; cw.Cbi = cbi; cw.taps = taps; cw.ntile = (Cout + 63) / 64;
   size_t off = pk.reserve(conv_pack_floats(Cout, cbi, taps));
-  conv_pack_host(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(), taps, pk.buf.data() + off);
+  conv_pack_host(wsrc, Cout, seg.data(), (int)seg.size(), taps, pk.buf.data() + off);
   fx.push_back({&cw.w, off});
   size_t boff = pk.reserve((size_t)cw.ntile * 64);
   const std::vector<float>& b = P(m, bkey);
@@ -484,7 +508,20 @@ extern "C" int tm_model_finalize(tm_model* m) {
     pack_raw(pk, fx, &m->gene.b1, P(m, g + ".mlp.fc1.bias"));
     pack_transposed(pk, fx, &m->gene.w2_t, P(m, g + ".mlp.fc2.weight"), d, 4 * d);
     pack_raw(pk, fx, &m->gene.b2, P(m, g + ".mlp.fc2.bias"));
-    pack_conv(m, pk, fx, m->downz, g + ".down_z.weight", g + ".down_z.bias", c.rna_num, {c.rna_num}, 27);
+    if (m->downz_mfma) pack_conv(m, pk, fx, m->downz, g + ".down_z.weight", g + ".down_z.bias", c.rna_num, {c.rna_num}, 27);
+    else {
+      static const int kzt[17] = {0, 1, 0, 0, 3, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0, 0, 9};            // MBAblocks.py:472
+      pack_direct(m, pk, fx, m->downz_d, g + ".down_z", c.rna_num, c.rna_num, kzt[c.rna_slc], 3, 3);
+    }
+    if (c.rna_num == 81) {                      // human-brain generalisation: the 81 shared genes (utils/__init__.py:49-57)
+      static const int M2H[81] = {1, 4, 5, 11, 21, 22, 23, 24, 25, 27, 35, 38, 40, 55, 56, 57, 61, 67, 69, 70, 75, 84, 90, 91, 96,
+                                  108, 111, 113, 118, 130, 134, 137, 139, 145, 152, 155, 158, 165, 170, 171, 179, 180, 189, 191,
+                                  206, 215, 223, 229, 230, 235, 241, 243, 253, 288, 297, 301, 309, 329, 337, 344, 346, 370, 372,
+                                  378, 380, 395, 410, 436, 441, 442, 443, 458, 465, 467, 472, 478, 487, 492, 493, 494, 496};
+      size_t off = pk.reserve(81);
+      memcpy(pk.buf.data() + off, M2H, sizeof(M2H));
+      fx.push_back({(const float**)&m->gene_idx, off});
+    }
   }
   if (!c.vis_only) {
     for (int rid = 1; rid < 4; ++rid)
@@ -511,8 +548,8 @@ extern "C" int tm_model_finalize(tm_model* m) {
         pack_conv_h(m, pk, fx, fxh, r.c1, &r.c1h, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg);
         pack_conv_h(m, pk, fx, fxh, r.c2, &r.c2h, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout});
       } else {
-        pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27);
-        pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27);
+        pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27, m->z == 1);
+        pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27, m->z == 1);
       }
       if (r.has_skip) {
         if (bf16) pack_linear_stack_h(m, pk, fx, fxh, r.skip, &r.skiph, {r.pfx + ".skip_connection"}, r.cout, r.seg);
@@ -915,12 +952,27 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
   TV tok = cx.tensor(Ne, c.rna_num, c.rna_slc, m->gn);           // gene-attention output, CB8 [Ne][Gb][zs][gn][gn][8]
   if (!cx.dry) {
     cx.check(hipMemsetAsync(tok.p, 0, (size_t)Ne * tok.nstride * sizeof(float), cx.s));      // pad gene slots
-    cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok.p, nullptr, 0, c.rna_slc, cx.s));
+    if (m->gene_mfma)
+      cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok.p, nullptr, 0, c.rna_slc, cx.s));
+  }
+  if (!m->gene_mfma) {
+    const size_t mark = cx.top;
+    float* gws = cx.alloc_f((size_t)Ne * gene_generic_ws_floats(c.rna_num, m->D));
+    if (!cx.dry)
+      cx.check(launch_gene_attn_generic(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->D, m->gene, m->gene_idx, tok.p, nullptr, 0,
+                                        c.rna_slc, gws, cx.s));
+    cx.top = mark;                                               // scratch only (the stream orders its reuse)
   }
   TV rl[4], rs[3];                                               // rna levels and SiLU(level) (pyramid + adaLN input)
   int S = m->gn * 2;
   rl[0] = cx.tensor(Ne, m->rw[0], Z, S);
-  run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
+  if (m->downz_mfma) run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
+  else {
+    // generic (kz, gn): direct conv straight from / to the CB8 tensors, nearest x2 fused into the store
+    const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl[0]);
+    if (!cx.dry) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));   // pad channels
+    run_direct(cx, m->downz_d, tok.p, ax, rl[0].p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+  }
   for (int i = 1; i < 4; ++i) {
     rs[i - 1] = cx.tensor(Ne, m->rw[i - 1], Z, S);
     if (!cx.dry) {
@@ -1061,21 +1113,30 @@ extern "C" int tm_pad_patchify(const void* img, void* patches, int b, int C, int
   return TM_OK;
 }
 
-extern "C" size_t tm_gene_attn_workspace_bytes(const tm_model* m, int B) { (void)m; (void)B; return 256; }
+extern "C" size_t tm_gene_attn_workspace_bytes(const tm_model* m, int B) {
+  if (!m || B < 1 || m->gene_mfma) return 256;
+  return 256 + (size_t)B * gene_generic_ws_floats(m->cfg.rna_num, m->D) * sizeof(float);
+}
 
 extern "C" int tm_gene_attn(tm_model* m, const void* rna_dense, int B, void* attn_out, void* rna_mid, void* workspace,
                             size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   if (!m || !rna_dense || !attn_out || B < 1) return fail(TM_ERR_ARG, "bad argument");
   if (!m->finalized) return fail(TM_ERR_STATE, "tm_model_finalize has not been called");
   const tm_config& c = m->cfg;
   const int G = c.rna_num, zs = c.rna_slc;
+  if (zs != 4) return fail(TM_ERR_ARG, "the attention-map read-out is defined for rna_slc = 4 (three slice pairs, model/unet_attn.py:162-172)");
+  if (workspace_bytes < tm_gene_attn_workspace_bytes(m, B) || (!m->gene_mfma && !workspace))
+    return fail(TM_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, tm_gene_attn_workspace_bytes(m, B));
   float* ao = (float*)attn_out;
   hipStream_t s = (hipStream_t)stream;
   // three slice-pair masks then the unmasked map (model/unet_attn.py:162-172)
   for (int i = 0; i < 4; ++i) {
     const int lo = (i < 3) ? i : 0, hi = (i < 3) ? i + 2 : zs;
-    HIP_TRY(launch_gene_attn((const float*)rna_dense, B, m->gn, zs, G, m->gene, nullptr, ao + (size_t)i * B * G * G, lo, hi, s));
+    if (m->gene_mfma)
+      HIP_TRY(launch_gene_attn((const float*)rna_dense, B, m->gn, zs, G, m->gene, nullptr, ao + (size_t)i * B * G * G, lo, hi, s));
+    else
+      HIP_TRY(launch_gene_attn_generic((const float*)rna_dense, B, m->gn, zs, G, m->D, m->gene, m->gene_idx, nullptr,
+                                       ao + (size_t)i * B * G * G, lo, hi, (float*)workspace, s));
   }
   if (rna_mid) HIP_TRY(launch_rna_mid((const float*)rna_dense, B, m->gn, zs, G, (float*)rna_mid, s));
   return TM_OK;

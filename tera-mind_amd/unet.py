@@ -185,8 +185,9 @@ class GeneAttnModel(_HipModel):
         attn = torch.empty((4, B, G, G), dtype=torch.float32, device=self.device)
         mid = torch.empty((B, G, zs - 2, gn, gn), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
+            ws = self._workspace(self._L.tm_gene_attn_workspace_bytes(self._h, B))
             _lib.check(self._L.tm_gene_attn(self._h, _lib.ptr(rna_d), B, _lib.ptr(attn), _lib.ptr(mid),
-                                            C.c_void_p(0), 0, _lib.current_stream_ptr()), "tm_gene_attn")
+                                            _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr()), "tm_gene_attn")
         return attn, mid
 
 

@@ -111,3 +111,23 @@ def test_attention_driver_readout_vs_reference_fixture():
         out = tc.attn_tile_readout(util.state_dict(cfg, vis_only=True), tc.oracle_config_from(cfg), tile, [75, 191])
     assert out.dtype == torch.float16 and tuple(out.shape[1:]) == gold.shape
     assert torch.equal(out[0].float(), torch.from_numpy(gold.astype(np.float32)))
+
+
+# ---- the other configuration-surface points -------------------------------------
+@pytest.mark.parametrize("case", __import__("config_cases").CONFIGS[:5] + [(64, 1, "all", 81)], ids=lambda c: __import__("config_cases").tag_of(c))
+def test_oracle_vs_reference_other_configs(case):
+    """oracle/teramind_cpu.py against outputs minted from the REAL reference (oracle/make_config_golden.py) for
+    patch_size 32 / 128, rna_slc 1 / 8 / 16, a single stain and the 81-gene M2H subset (a CPU subset of the list the
+    GPU suite covers; each forward takes seconds)."""
+    import config_cases as cc
+    from oracle import teramind_cpu as tc
+    from teramind_amd.weights import hashed_state_dict
+    gold = np.load(os.path.join(util.GOLDEN, "unet_configs.npz"))
+    cfg = cc.path_config(case)
+    x, rna, t = cc.inputs(cfg)
+    torch.set_num_threads(8)
+    with torch.inference_mode():
+        pred, pred2 = tc.unet_forward(hashed_state_dict(cfg, 0), tc.oracle_config_from(cfg), x, t, rna, 2, 2, want_pred2=True)
+    for name, got in (("pred", pred), ("pred2", pred2)):
+        ref = gold[f"{cc.tag_of(case)}/{name}"]
+        assert np.abs(cc.digest(got) - ref).max() < 5e-5, (case, name)
