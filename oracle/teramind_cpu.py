@@ -517,20 +517,22 @@ def gene_tile_names(size=256, hst=256, wst=256, hnm=286, wnm=414) -> List[str]:
 
 
 def zchunk_state(out: Tensor, total_slc: int, z_size: int) -> Tensor:
-    """'b h w (s z)' (z=total_slc) -> '(n_z b) h w (s z)' with z = z_size//2.  test_brn.py:188-192"""
+    """'b h w (s z)' (z=total_slc) -> '(n_z b) h w (s z)' with z = z_size//2 (test_brn.py:188-192);
+    z_size 1: '(z b) h w s', one slice per model call (test_brn.py:183-185)."""
     b, h, w, sz = out.shape
     s = sz // total_slc
-    zc = z_size // 2
+    zc = max(1, z_size // 2)
     nz = total_slc // zc
     o = out.reshape(b, h, w, s, nz, zc).permute(4, 0, 1, 2, 3, 5)
     return o.reshape(nz * b, h, w, s * zc)
 
 
 def zchunk_rna(rna: Tensor, z_size: int) -> Tensor:
-    """'b h w (z g)' -> unfold(z, z_size, z_size//2) -> '(n_s b) h w (s g)'.  test_brn.py:193-197"""
+    """'b h w (z g)' -> unfold(z, z_size, z_size//2) -> '(n_s b) h w (s g)' (test_brn.py:193-197);
+    z_size 1: '(z b) h w g' (test_brn.py:186-187) = windows of one slice."""
     b, h, w, zg = rna.shape
     zt = zg // 500
-    r = rna.reshape(b, h, w, zt, 500).unfold(3, z_size, z_size // 2)        # b h w n_s g s
+    r = rna.reshape(b, h, w, zt, 500).unfold(3, z_size, max(1, z_size // 2))        # b h w n_s g s
     ns = r.shape[3]
     return r.permute(3, 0, 1, 2, 5, 4).reshape(ns * b, h, w, z_size * 500)
 

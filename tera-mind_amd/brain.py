@@ -53,8 +53,11 @@ class TileSweep:
         if state not in ("fp32x2", "fp16"):
             raise ValueError(f"state {state!r}")
         self.state = state
-        if conf.rna_slc not in (4, 8, 16):
-            raise NotImplementedError("TileSweep implements the z-chunked configs (rna_slc in 4, 8, 16)")
+        if conf.rna_slc not in (1, 4, 8, 16):
+            raise NotImplementedError("rna_slc must be 1, 4, 8 or 16")
+        if total_slc % max(1, conf.rna_slc // 2):
+            raise ValueError(f"total_slc {total_slc} is not a multiple of the z chunk {conf.rna_slc // 2} "
+                             f"(the reference uses tiles.state_slices(rna_slc) = {tiles.state_slices(conf.rna_slc)})")
         self.conf, self.sampler, self.model, self.gene = conf, sampler, model, gene_provider
         self.hnm, self.wnm, self.T = hnm, wnm, total_epochs
         self.row0, self.col0 = hst // tiles.TILE, wst // tiles.TILE          # MBADataset_tst.py:33
@@ -266,7 +269,8 @@ class TileSweep:
 
 def synthetic_gene_provider(conf: PathConfig, total_slc: int = 50, density: float = 0.02, device="cpu"):
     """Config-3 synthetic genes: a [20, 20, 26000] tile seeded by the tile
-    index; zero in the z-padding slices like MBADataset_tst._getgene."""
+    index; zero in the z-padding slices like MBADataset_tst._getgene.  total_slc = GENE slices (50 in the
+    reference data, also for the 8- / 16-slice models whose state has 48)."""
     from . import synth
     zpad = Z_PAD[conf.rna_slc]
     cells = (tiles.TILE + 2 * PAD) // (conf.patch_size // conf.gn_sz)
@@ -288,6 +292,8 @@ class GeneTileDir:
     (block sum + halo shift + crop + z padding in one scatter pass)."""
 
     def __init__(self, gdir, conf: PathConfig, device, total_slc: int = 50, keep_resident: bool = True):
+        """total_slc: slices in the gene files (50 for every config; the 8- / 16-slice models keep 48 STATE slices,
+        tiles.state_slices, but read all 50 gene slices plus z padding)."""
         import os
         self.gdir, self.conf, self.dev = str(gdir), conf, torch.device(device)
         self.gblk = conf.patch_size // conf.gn_sz                      # test_brn.py:282 `_blk`

@@ -51,6 +51,13 @@ def state_tile_name(row: int, col: int, size: int = TILE) -> str:
     return f"{row * size}_{(row + 1) * size}_{col * size}_{(col + 1) * size}"
 
 
+def state_slices(rna_slc: int) -> int:
+    """Brain slices held in a state tile: 48 for the 8- and 16-slice models (their z windows of 8 / 16 gene slices,
+    stride 4 / 8, centre on 4 / 8 state slices and the outermost gene slices have no state), 50 otherwise
+    (test_brn.py:277-278 `_chn`)."""
+    return 48 if rna_slc in (8, 16) else 50
+
+
 def row_block_partition(hnm: int, world: int) -> List[Tuple[int, int]]:
     """[r0, r1) tile rows per rank: contiguous blocks, sizes differ by at most one row."""
     base, extra = divmod(hnm, world)
@@ -64,17 +71,19 @@ def row_block_partition(hnm: int, world: int) -> List[Tuple[int, int]]:
 
 # ---- Tester._run_batch layout maps ---------------------------------------------------------
 def zchunk_state(tile: torch.Tensor, total_slc: int, z_size: int) -> torch.Tensor:
-    """[b, h, w, (s z)] with z = total_slc  ->  [(n_z b), h, w, (s zc)], zc = z_size // 2."""
+    """[b, h, w, (s z)] with z = total_slc  ->  [(n_z b), h, w, (s zc)], zc = z_size // 2
+    (test_brn.py:188-192); z_size 1: one slice per model call, '(z b) h w s' (test_brn.py:183-185)."""
     b, h, w, sz = tile.shape
-    s, zc = sz // total_slc, z_size // 2
+    s, zc = sz // total_slc, max(1, z_size // 2)
     nz = total_slc // zc
     return tile.reshape(b, h, w, s, nz, zc).permute(4, 0, 1, 2, 3, 5).reshape(nz * b, h, w, s * zc)
 
 
 def zchunk_rna(rna: torch.Tensor, z_size: int) -> torch.Tensor:
-    """[b, h, w, (z g)] -> windows of z_size slices, stride z_size//2 -> [(n_s b), h, w, (s g)]."""
+    """[b, h, w, (z g)] -> windows of z_size slices, stride z_size//2 -> [(n_s b), h, w, (s g)]
+    (test_brn.py:193-197); z_size 1: '(z b) h w g' (test_brn.py:186-187)."""
     b, h, w, zg = rna.shape
-    win = rna.reshape(b, h, w, zg // GENES, GENES).unfold(3, z_size, z_size // 2)      # b h w n_s g s
+    win = rna.reshape(b, h, w, zg // GENES, GENES).unfold(3, z_size, max(1, z_size // 2))      # b h w n_s g s
     ns = win.shape[3]
     return win.permute(3, 0, 1, 2, 5, 4).reshape(ns * b, h, w, z_size * GENES)
 
@@ -97,7 +106,7 @@ def regroup_output(out: torch.Tensor, b: int, n_stain: int) -> torch.Tensor:
 
 def run_batch_inputs(tile_hwc: torch.Tensor, rna_hwc: torch.Tensor, patch_size: int, gn_sz: int, total_slc: int,
                      z_size: int):
-    """The tensors Tester._run_batch hands to sampler.sample for rna_slc in (4, 8, 16):
+    """The tensors Tester._run_batch hands to sampler.sample for rna_slc in (1, 4, 8, 16):
     returns (x_patches [(n_z b p1 p2), C, ps, ps], rna_patches [(n_s b p1 p2), gn, gn, z_size*500],
     shape (n_z*b, C, H-ps, W-ps))."""
     x = zchunk_state(tile_hwc, total_slc, z_size)

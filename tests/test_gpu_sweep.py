@@ -58,3 +58,27 @@ def test_tile_sweep_single_fp16_canvas_equals_two_canvas_state():
     b = sw.test()
     assert b.dtype == torch.float16 and sw.nxt is None
     assert torch.equal(b.float(), a)
+
+
+@pytest.mark.parametrize("rna_slc,state_slc,gene_slc", [(1, 2, 2), (8, 8, 10)])
+def test_tile_sweep_other_rna_slc(rna_slc, state_slc, gene_slc):
+    """The sweep for the per-slice model (rna_slc 1) and a z_size-4 model (rna_slc 8: state slices = gene slices - 2,
+    like the reference's 48 / 50): one tile, one DDIM step, HIP vs the oracle-driven sweep."""
+    cfg = PathConfig(rna_slc=rna_slc)
+    sd = util.state_dict(cfg)
+    genes = synthetic_gene_provider(cfg, total_slc=gene_slc)
+    kw = dict(hst=256, wst=512, hnm=1, wnm=1, total_epochs=T, total_slc=state_slc)
+
+    class OneStep(OracleSampler):
+        pass
+
+    ref_sw = TileSweep(cfg, OneStep(cfg, sd), None, genes, device="cpu", **kw)
+    ref_sw.step()
+    ref = ref_sw.local_state()
+    model = BeatGANsUNetModel(cfg, DEV).load_state_dict(sd)
+    sw = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, device=DEV, **kw)
+    sw.step()
+    got = sw.local_state()
+    assert got.shape == (state_slc * 2, 256, 256)
+    d = (got.cpu() - ref).abs()
+    assert d.max() <= 2e-3 and d.mean() <= 2e-5, util.report("sweep", got, ref)

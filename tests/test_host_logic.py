@@ -137,3 +137,36 @@ def test_hashed_generator_is_pure_function_of_key_and_index():
     assert float(np.abs(z).max()) > 0            # zero_module convs are overwritten
     sd = strip_lightning_state_dict({"state_dict": {"model.out.0.weight": 1, "ema_model.out.0.weight": 2}})
     assert sd == {"out.0.weight": 1}
+
+
+@pytest.mark.parametrize("z", [1, 8, 16])
+def test_run_batch_layout_maps_other_z_vs_reference(z):
+    """rna_slc 1 (per-slice path) and 8 / 16 (48 state slices, 50 gene slices + z padding): the index maps against
+    what the reference's Tester._run_batch produced (oracle/make_tile_z_golden.py)."""
+    rb = json.load(open(os.path.join(util.GOLDEN, "run_batch_z.json")))[str(z)]
+    total, gch = rb["total_slc"], rb["gene_channels"]
+    assert total == tiles.state_slices(z)
+    chn = total * 2
+    tile = torch.arange(320 * 320 * chn, dtype=torch.float32).reshape(1, 320, 320, chn)
+    gen = torch.Generator().manual_seed(rb["seed"])
+    ssz = (1, 20, 20, gch)
+    crd = torch.stack([torch.randint(0, ssz[k], (4000,), generator=gen) for k in range(4)])
+    crd = torch.unique(crd, dim=1)
+    dat = (crd[1] * 20 * gch + crd[2] * gch + crd[3] + 1).float()
+    rna = torch.sparse_coo_tensor(crd, dat, ssz).to_dense()
+    x, r, shape = tiles.run_batch_inputs(tile, rna, 64, 4, total, z)
+    assert list(shape) == rb["shape"] and list(x.shape) == rb["imgs_shape"] and list(r.shape) == rb["rna_shape"]
+    assert x[:, 1, 5, 7].long().tolist() == rb["imgs_probe"] and float(x.double().sum()) == rb["imgs_sum"]
+    assert int((r != 0).sum()) == rb["rna_nonzero"] and float(r.double().sum()) == rb["rna_sum"]
+    for n, probe in zip(rb["rna_probe_rows"], rb["rna_probe"]):
+        assert [int(v) for v in r[n].nonzero()[:3].reshape(-1).tolist()] + [float(r[n].max())] == probe
+    assert torch.equal(tc.zchunk_state(tile, total, z), tiles.zchunk_state(tile, total, z))
+    assert torch.equal(tc.zchunk_rna(rna, z), tiles.zchunk_rna(rna, z))
+    n, cz = shape[0], shape[1]
+    out = (torch.arange(n * cz * 256 * 256, dtype=torch.float32).reshape(n, cz, 256, 256) % 2039) / 64.0
+    saved = tiles.regroup_output(out, 1, 2).half()
+    assert list(saved.shape[1:]) == rb["saved_shape"] and rb["saved_dtype"] == "float16"
+    f = saved[0].float().reshape(-1)
+    d = rb["saved_digest"]
+    assert torch.equal(f[torch.tensor(d["idx"])].double(), torch.tensor(d["val"], dtype=torch.float64))
+    assert abs(float(f.double().mean()) - d["mean"]) <= 1e-9
