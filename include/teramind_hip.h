@@ -47,8 +47,8 @@ enum { TM_SAMPLE_DDPM = 0, TM_SAMPLE_DDIM = 1 };
 /* Model configuration.  Replaces BeatGANsUNetConfig as filled by
  * TrainConfig.make_model_conf (config.py:280-326) from prep_config_parm (config_parm.py:5-59). */
 typedef struct tm_config {
-  int32_t patch_size;     /* image_size / patch_size: 64 */
-  int32_t rna_slc;        /* len(rna_tpl): 4   -> z_size = ceil(rna_slc/2) */
+  int32_t patch_size;     /* image_size / patch_size: 32 | 64 | 128 (config_parm.py:47-55; 64 = the published checkpoint) */
+  int32_t rna_slc;        /* len(rna_tpl): 1 | 4 | 8 | 16 (train.py:24-26) -> z_size = ceil(rna_slc/2); gn^2 * rna_slc <= 512 */
   int32_t n_stain;        /* 2 for stain='all', else 1 */
   int32_t rna_num;        /* 229 */
   int32_t net_ch;         /* model_channels: 64 */
@@ -165,7 +165,8 @@ int tm_blosc_decompress(const void* src, size_t src_bytes, void* dst, size_t dst
  * event, adds up the bracketed durations and the per-launch work, and resets the counters.
  *   nominal_flops  = 2*Cin*Cout*27*voxels per launch (dense-conv convention; what
  *                    torch.utils.flop_counter counts for the reference's Conv3d)
- *   executed_flops = 2/3 of that: the always-zero z tap is not issued (Z == 2)
+ *   executed_flops = 2/3 of that for z_size 2 (the always-zero z tap is not issued), 1/3 for z_size 1 (centre
+ *                    slice only), all of it for z_size 4 / 8
  *   alg_bytes      = input + packed weights + output bytes, each counted once per launch */
 typedef struct tm_prof_stats {
   uint64_t launches;

@@ -614,7 +614,8 @@ extern "C" int tm_profile_collect(tm_model* m, tm_prof_stats* out) {
   }
   out->launches = m->prof_used;
   out->nominal_flops = m->prof_nominal;
-  out->executed_flops = m->prof_nominal * (18.0 / 27.0);
+  // Z == 2: the z-skip form issues 18 of 27 taps; Z == 1: the centre slice only (9); Z >= 3: all 27 (zero planes staged)
+  out->executed_flops = m->prof_nominal * (m->z == 2 ? 18.0 / 27.0 : (m->z == 1 ? 9.0 / 27.0 : 1.0));
   out->alg_bytes = m->prof_bytes;
   m->prof_used = 0; m->prof_nominal = 0; m->prof_bytes = 0;
   return TM_OK;
@@ -694,7 +695,7 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
   ConvLaunch L;
   L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags; L.zmode = zmode;
   tm_model* m = cx.m;
-  const bool prof = m->prof_on && w.taps == 27 && zmode == ZM_PAD1;
+  const bool prof = m->prof_on && (w.taps == 27 || (m->z == 1 && w.taps == 9)) && zmode == ZM_PAD1;
   if (prof) {
     if (m->prof_used == m->prof_ev.size()) {
       hipEvent_t a, b;
