@@ -174,7 +174,9 @@ struct GeneW {       // all device pointers; matrices stored TRANSPOSED [in][out
 hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, const GeneW& w,
                             float* out_tok /*nullable*/, float* attn_map /*nullable [B][G][G]*/,
                             int zmask_lo, int zmask_hi, hipStream_t s);
-// generic G <= 512, D <= 512 form (global scratch `ws`: B * gene_generic_ws_floats(G, D) floats; gidx: gene slot table or null)
+// generic G <= 512, D <= 512 form (global scratch `ws`: B * gene_generic_split(B) * gene_generic_ws_floats(G, D) floats;
+// gidx: gene slot table or null)
+int gene_generic_split(int B);
 size_t gene_generic_ws_floats(int G, int D);
 hipError_t launch_gene_attn_generic(const float* rna, int B, int gn, int zs, int G, int D, const GeneW& w, const int* gidx,
                                     float* out_tok, float* attn_map, int zmask_lo, int zmask_hi, float* ws, hipStream_t s);

@@ -1372,11 +1372,11 @@ __global__ __launch_bounds__(256) void gene_attn_generic_kernel(GeneGenArgs ga) 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = blockIdx.x;
   const int gg = a.gn * a.gn;
-  float* tok = ga.ws + (long)n * ga.ws_stride;     // [G][D], later the MLP hidden [G][4D]
+  float* tok = ga.ws + ((long)n * gridDim.y + blockIdx.y) * ga.ws_stride;     // [G][D], later the MLP hidden [G][4D]
   float* qn = tok + (long)G * 4 * D;                // [G][D]
   float* qnT = qn + (long)G * D;                    // [D][Gp]
   float* pt = qnT + (long)D * Gp;                   // [G][D]  P.tok, then norm2 output
-  float* xs = sm + wv * (GG_RB * 4 * D + Gp);       // per wave: RB rows x up to 4D inputs, then Gp softmax row
+  float* xs = sm + wv * GG_RB * (4 * D + Gp);       // per wave: RB rows x up to 4D inputs, then RB softmax rows [Gp]
   float* pr = xs + GG_RB * 4 * D;
   const long rbase = (long)n * gg * a.zs * 500;
   for (int i = tid; i < G * D; i += 256) {
@@ -1420,45 +1420,66 @@ __global__ __launch_bounds__(256) void gene_attn_generic_kernel(GeneGenArgs ga) 
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  // ---- P = softmax(qn.qn^T / D) row by row; pt = P.tok ----
+  // ---- P = softmax(qn.qn^T / D), RB query rows per wave at a time; pt = P.tok ----
+  // (gridDim.y workgroups share a patch's rows of this pass and of the MLP pass; each has its own scratch slab)
   const int NJ = Gp / 64;                             // <= 8 key chunks per lane
-  for (int g = wv; g < G; g += 4) {
-    for (int i = lane; i < D; i += 64) xs[i] = qn[(long)g * D + i];
+  const int row0 = (wv + 4 * blockIdx.y) * GG_RB, rstep = 4 * GG_RB * gridDim.y;
+  for (int g0 = row0; g0 < G; g0 += rstep) {
+    for (int i = lane; i < GG_RB * D; i += 64) { const int r = i / D; xs[i] = qn[(long)min(g0 + r, G - 1) * D + i - r * D]; }
     __builtin_amdgcn_wave_barrier();
-    float lg[8];
+    float lg[8][GG_RB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) lg[j] = 0.f;
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) lg[j][r] = 0.f;
     for (int d = 0; d < D; ++d) {
-      const float qv = xs[d];
       const float* kr = qnT + (long)d * Gp + lane;
+      float qv[GG_RB];
+#pragma unroll
+      for (int r = 0; r < GG_RB; ++r) qv[r] = xs[r * D + d];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < NJ) lg[j] = fmaf(qv, kr[64 * j], lg[j]);
+        if (j < NJ) {
+          const float kv = kr[64 * j];
+#pragma unroll
+          for (int r = 0; r < GG_RB; ++r) lg[j][r] = fmaf(qv[r], kv, lg[j][r]);
+        }
     }
-    float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < NJ) { lg[j] *= inv_d; if (lane + 64 * j < G) m = fmaxf(m, lg[j]); }      // (q*scale).(k)*scale, scale = D^-1/2
-    m = wave_max(m);
-    float ssum = 0.f;
+    for (int r = 0; r < GG_RB; ++r) {
+      float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < NJ) { lg[j] = (lane + 64 * j < G) ? expf(lg[j] - m) : 0.f; ssum += lg[j]; }
-    ssum = wave_sum(ssum);
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) { lg[j][r] *= inv_d; if (lane + 64 * j < G) m = fmaxf(m, lg[j][r]); }   // (q*scale).(k)*scale, scale = D^-1/2
+      m = wave_max(m);
+      float ssum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < NJ) {
-        const int u = lane + 64 * j;
-        const float p = lg[j] / ssum;
-        pr[u] = p;
-        if (a.attn_map && u < G) a.attn_map[((long)n * G + g) * G + u] = p;
-      }
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) { lg[j][r] = (lane + 64 * j < G) ? expf(lg[j][r] - m) : 0.f; ssum += lg[j][r]; }
+      ssum = wave_sum(ssum);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NJ) {
+          const int u = lane + 64 * j;
+          const float p = lg[j][r] / ssum;
+          pr[r * Gp + u] = p;
+          if (a.attn_map && u < G && g0 + r < G) a.attn_map[((long)n * G + g0 + r) * G + u] = p;
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     if (a.out_tok) {
       for (int c = lane; c < D; c += 64) {
-        float acc = 0.f;
-        for (int u = 0; u < G; ++u) acc = fmaf(pr[u], tok[(long)u * D + c], acc);
-        pt[(long)g * D + c] = acc;
+        float acc[GG_RB];
+#pragma unroll
+        for (int r = 0; r < GG_RB; ++r) acc[r] = 0.f;
+#pragma unroll 4
+        for (int u = 0; u < G; ++u) {
+          const float tv = tok[(long)u * D + c];
+#pragma unroll
+          for (int r = 0; r < GG_RB; ++r) acc[r] = fmaf(pr[r * Gp + u], tv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < GG_RB; ++r) if (g0 + r < G) pt[(long)(g0 + r) * D + c] = acc[r];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1467,7 +1488,7 @@ __global__ __launch_bounds__(256) void gene_attn_generic_kernel(GeneGenArgs ga) 
   __syncthreads();
   // ---- ov = Wv.pt + bv; op = Wp.ov + bp; norm2; MLP ----
   float* hrow = tok;                                  // [G][4D] MLP hidden: tok is dead (every wave is past the P.tok pass)
-  for (int g0 = wv * GG_RB; g0 < G; g0 += 4 * GG_RB) {
+  for (int g0 = row0; g0 < G; g0 += rstep) {
     float* x0 = xs;                                   // [RB][D]
     float* x1 = xs + GG_RB * D;                       // [RB][D]
     for (int i = lane; i < GG_RB * D; i += 64) { const int r = i / D; x0[i] = (g0 + r < G) ? pt[(long)(g0 + r) * D + i - r * D] : 0.f; }
@@ -1508,7 +1529,9 @@ __global__ __launch_bounds__(256) void gene_attn_generic_kernel(GeneGenArgs ga) 
   }
 }
 
-size_t gene_generic_ws_floats(int G, int D) {
+int gene_generic_split(int B) { return B >= 512 ? 1 : (B >= 256 ? 2 : 4); }   // workgroups per patch (rows of the heavy passes)
+
+size_t gene_generic_ws_floats(int G, int D) {                                   // per (patch, share) slab
   const size_t Gp = (size_t)(G + 63) / 64 * 64;
   // tok [G][D] (reused as the MLP hidden [G][4D]) + qn [G][D] + qnT [D][Gp] + pt [G][D]
   return (size_t)G * 4 * D + (size_t)G * D + (size_t)D * Gp + (size_t)G * D;
@@ -1522,7 +1545,7 @@ hipError_t launch_gene_attn_generic(const float* rna, int B, int gn, int zs, int
   ga.g.out_tok = out_tok; ga.g.attn_map = attn_map; ga.g.scratch = nullptr; ga.g.zlo = zlo; ga.g.zhi = zhi;
   ga.D = D; ga.gidx = gidx; ga.ws = ws; ga.ws_stride = (long)gene_generic_ws_floats(G, D);
   const int Gp = (G + 63) / 64 * 64;
-  const size_t lds = (size_t)4 * (GG_RB * 4 * D + Gp) * sizeof(float);
+  const size_t lds = (size_t)4 * GG_RB * (4 * D + Gp) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gene_attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1530,7 +1553,7 @@ hipError_t launch_gene_attn_generic(const float* rna, int B, int gn, int zs, int
     attr_set = true;
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gene_attn_generic_kernel, dim3(B), dim3(256), lds, s, ga);
+  hipLaunchKernelGGL(gene_attn_generic_kernel, dim3(B, gene_generic_split(B)), dim3(256), lds, s, ga);
   return hipGetLastError();
 }
 
@@ -1873,8 +1896,10 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
 
 
 // ---- generic windowed attention core: any window size T = Z*(S/2)^2 <= 512, C <= 512 (fp32, VALU) ------------------
-// The other patch_size / rna_slc configurations (T = 8 ... 512).  One workgroup per (patch, window), one query per wave at
-// a time: lanes = keys for the logits, lanes = channel blocks for P.V.  < 0.5 % of the FLOPs; correctness first.
+// The other patch_size / rna_slc configurations (T = 8 ... 512).  One workgroup per (patch, window); a wave works on
+// WQ queries at a time so that every K / V fragment it loads feeds WQ dot products / accumulations: lanes = keys for the
+// logits, lanes = channel blocks for P.V.  < 0.5 % of the FLOPs; correctness first.
+#define WQ 4
 __global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int T) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = a.C, Cb = C / 8;
@@ -1883,8 +1908,8 @@ __global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int
   float* rk = rq + T;                      // [T]
   float* w2 = rk + T;                      // [C]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float* qrow = w2 + C + wv * (C + T);     // [C]
-  float* prow = qrow + C;                  // [T]
+  float* qrow = w2 + C + wv * WQ * (C + T);   // [WQ][C]
+  float* prow = qrow + WQ * C;                // [WQ][T]
   const int n = blockIdx.x >> 2, win = blockIdx.x & 3;
   const int wy = win >> 1, wx = win & 1;
   const int S = a.S, hs = S / 2;
@@ -1914,51 +1939,78 @@ __global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int
   }
   __syncthreads();
   const int NJ = (T + 63) / 64;            // <= 8 key chunks per lane
-  for (int t = wv; t < T; t += 4) {
-    const float sq = rq[t] / (float)C;     // (q*scale).(k*scale), scale = C^-1/2 (MBAblocks.py:571-577)
-    for (int c = lane; c < C; c += 64) qrow[c] = qb[tokoff[t] + (long)(c >> 3) * a.plane + (c & 7)] * w2[c] * sq;
+  for (int t0 = wv * WQ; t0 < T; t0 += 4 * WQ) {
+    // (q*scale).(k*scale), scale = C^-1/2 (MBAblocks.py:571-577); queries past T replicate the last one (never stored)
+    for (int i = lane; i < WQ * C; i += 64) {
+      const int r = i / C, c = i - r * C;
+      const int t = min(t0 + r, T - 1);
+      qrow[i] = qb[tokoff[t] + (long)(c >> 3) * a.plane + (c & 7)] * w2[c] * (rq[t] / (float)C);
+    }
     __builtin_amdgcn_wave_barrier();
-    float lg[8];
+    float lg[8][WQ];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      lg[j] = -INFINITY;
       const int u = lane + 64 * j;
-      if (j < NJ && u < T) {
+      const bool ok = j < NJ && u < T;
+      float acc[WQ];
+#pragma unroll
+      for (int r = 0; r < WQ; ++r) acc[r] = 0.f;
+      if (ok) {
         const float* kp = kb + tokoff[u];
-        float acc = 0.f;
         for (int cb = 0; cb < Cb; ++cb) {
           const f32x4 k0 = *(const f32x4*)(kp + (long)cb * a.plane), k1 = *(const f32x4*)(kp + (long)cb * a.plane + 4);
-          const float* qc = qrow + cb * 8;
-          acc += qc[0] * k0[0] + qc[1] * k0[1] + qc[2] * k0[2] + qc[3] * k0[3] + qc[4] * k1[0] + qc[5] * k1[1] +
-                 qc[6] * k1[2] + qc[7] * k1[3];
+#pragma unroll
+          for (int r = 0; r < WQ; ++r) {
+            const float* qc = qrow + r * C + cb * 8;
+            acc[r] += qc[0] * k0[0] + qc[1] * k0[1] + qc[2] * k0[2] + qc[3] * k0[3] + qc[4] * k1[0] + qc[5] * k1[1] +
+                      qc[6] * k1[2] + qc[7] * k1[3];
+          }
         }
-        lg[j] = acc * rk[u];
       }
+      const float rku = ok ? rk[u] : 0.f;
+#pragma unroll
+      for (int r = 0; r < WQ; ++r) lg[j][r] = ok ? acc[r] * rku : -INFINITY;
     }
-    float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, lg[j]);
-    m = wave_max(m);
-    float ssum = 0.f;
+    for (int r = 0; r < WQ; ++r) {
+      float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { lg[j] = (lg[j] == -INFINITY) ? 0.f : expf(lg[j] - m); ssum += lg[j]; }
-    ssum = wave_sum(ssum);
-    const float inv = 1.0f / ssum;
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, lg[j][r]);
+      m = wave_max(m);
+      float ssum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int u = lane + 64 * j; if (j < NJ && u < T) prow[u] = lg[j] * inv; }
+      for (int j = 0; j < 8; ++j) { lg[j][r] = (lg[j][r] == -INFINITY) ? 0.f : expf(lg[j][r] - m); ssum += lg[j][r]; }
+      ssum = wave_sum(ssum);
+      const float inv = 1.0f / ssum;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int u = lane + 64 * j; if (j < NJ && u < T) prow[r * T + u] = lg[j][r] * inv; }
+    }
     __builtin_amdgcn_wave_barrier();
     for (int cb = lane; cb < Cb; cb += 64) {
-      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float o[WQ][8];
+#pragma unroll
+      for (int r = 0; r < WQ; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[r][j] = 0.f;
       const float* vp = vb + (long)cb * a.plane;
+#pragma unroll 2
       for (int u = 0; u < T; ++u) {
-        const float p = prow[u];
         const f32x4 v0 = *(const f32x4*)(vp + tokoff[u]), v1 = *(const f32x4*)(vp + tokoff[u] + 4);
-        o[0] = fmaf(p, v0[0], o[0]); o[1] = fmaf(p, v0[1], o[1]); o[2] = fmaf(p, v0[2], o[2]); o[3] = fmaf(p, v0[3], o[3]);
-        o[4] = fmaf(p, v1[0], o[4]); o[5] = fmaf(p, v1[1], o[5]); o[6] = fmaf(p, v1[2], o[6]); o[7] = fmaf(p, v1[3], o[7]);
+#pragma unroll
+        for (int r = 0; r < WQ; ++r) {
+          const float p = prow[r * T + u];
+          o[r][0] = fmaf(p, v0[0], o[r][0]); o[r][1] = fmaf(p, v0[1], o[r][1]); o[r][2] = fmaf(p, v0[2], o[r][2]);
+          o[r][3] = fmaf(p, v0[3], o[r][3]); o[r][4] = fmaf(p, v1[0], o[r][4]); o[r][5] = fmaf(p, v1[1], o[r][5]);
+          o[r][6] = fmaf(p, v1[2], o[r][6]); o[r][7] = fmaf(p, v1[3], o[r][7]);
+        }
       }
-      float* op = a.o + (long)n * a.o_ns + tokoff[t] + (long)cb * a.plane;
-      *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
-      *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+#pragma unroll
+      for (int r = 0; r < WQ; ++r) {
+        if (t0 + r >= T) break;
+        float* op = a.o + (long)n * a.o_ns + tokoff[t0 + r] + (long)cb * a.plane;
+        *(f32x4*)op = f32x4{o[r][0], o[r][1], o[r][2], o[r][3]};
+        *(f32x4*)(op + 4) = f32x4{o[r][4], o[r][5], o[r][6], o[r][7]};
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1988,7 +2040,13 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
   const int T = q.Z * (q.H / 2) * (q.H / 2);
   if ((T != 128 && T != 32) || a.C % 128) {            // the other configurations: generic kernel (fp32 output only)
     if (T > 512 || a.C > 512 || o_h) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)3 * T + a.C + 4 * (a.C + T)) * sizeof(float);
+    const size_t lds = ((size_t)3 * T + a.C + 4 * WQ * (a.C + T)) * sizeof(float);
+    static bool gattr = false;
+    if (!gattr) {
+      hipError_t e = hipFuncSetAttribute((const void*)window_attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      gattr = true;
+    }
     hipLaunchKernelGGL(window_attn_generic_kernel, dim3(q.N * 4), dim3(256), lds, s, a, T);
     return hipGetLastError();
   }

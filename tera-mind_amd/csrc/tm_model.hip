@@ -958,7 +958,7 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
   }
   if (!m->gene_mfma) {
     const size_t mark = cx.top;
-    float* gws = cx.alloc_f((size_t)Ne * gene_generic_ws_floats(c.rna_num, m->D));
+    float* gws = cx.alloc_f((size_t)Ne * gene_generic_split(Ne) * gene_generic_ws_floats(c.rna_num, m->D));
     if (!cx.dry)
       cx.check(launch_gene_attn_generic(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->D, m->gene, m->gene_idx, tok.p, nullptr, 0,
                                         c.rna_slc, gws, cx.s));
@@ -1116,7 +1116,7 @@ extern "C" int tm_pad_patchify(const void* img, void* patches, int b, int C, int
 
 extern "C" size_t tm_gene_attn_workspace_bytes(const tm_model* m, int B) {
   if (!m || B < 1 || m->gene_mfma) return 256;
-  return 256 + (size_t)B * gene_generic_ws_floats(m->cfg.rna_num, m->D) * sizeof(float);
+  return 256 + (size_t)B * gene_generic_split(B) * gene_generic_ws_floats(m->cfg.rna_num, m->D) * sizeof(float);
 }
 
 extern "C" int tm_gene_attn(tm_model* m, const void* rna_dense, int B, void* attn_out, void* rna_mid, void* workspace,

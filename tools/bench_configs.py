@@ -21,6 +21,8 @@ from teramind_amd.weights import hashed_state_dict  # noqa: E402
 dev = "cuda:0"
 CASES = [(64, 4, "all", 229, 32), (64, 1, "all", 229, 32), (64, 8, "all", 229, 16), (64, 16, "all", 229, 8), (32, 4, "all", 229, 64),
          (128, 4, "all", 229, 8), (64, 4, "all", 500, 32), (64, 1, "all", 81, 32)]
+if os.environ.get("TM_CASE"):
+    CASES = [CASES[int(i)] for i in os.environ["TM_CASE"].split(",")]
 for size, srna, stain, nrna, b in CASES:
     cfg = PathConfig(patch_size=size, rna_slc=srna, stain=stain, rna_num=nrna)
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
