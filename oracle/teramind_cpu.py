@@ -616,3 +616,37 @@ def stitch_tile_uint8(tile_f16, slc: int = 50):
     c = g.shape[0] // slc
     g = g.reshape(c, slc, *g.shape[1:]).swapaxes(0, 1).reshape(g.shape)
     return ((g + 1) * 127.5).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------
+# Training objective, forward half
+def training_losses(W, cfg: OracleConfig, sch: Schedule, x_start: Tensor, r_start, t: Tensor, loss_mask: Tensor,
+                    noise: Tensor, ix: int, iy: int, patch_size: int = 64, loss_type: str = "mse"):
+    """diffusion/base.py:181-289 with the two random.randrange draws given as (ix, iy) and the model in eval mode:
+    q_sample (:141-158) -> mask -> 2x2-patch crop of image, noise, mask and COO genes (:222-247) -> forward with
+    do_train (p1 = p2 = 2, unet_ours.py:364-365) -> mse / l1 of pred vs the centre-shifted noise and of pred2 vs the
+    patch noise under the mask (:272-288).  Returns (loss, x_t)."""
+    import numpy as np
+    halfp = patch_size // 2
+    rep = x_start.shape[0] // t.shape[0]
+    t_cur = t.repeat_interleave(rep)
+    a = torch.from_numpy(np.sqrt(sch.alphas_cumprod))[t_cur].float().reshape(-1, 1, 1, 1)
+    b = torch.from_numpy(np.sqrt(1.0 - sch.alphas_cumprod))[t_cur].float().reshape(-1, 1, 1, 1)
+    x_t = (a * x_start + b * noise) * loss_mask
+    dat, crd, ssz = r_start
+    r_size = patch_size // (x_start.shape[2] // ssz[1])
+    crd = crd.long().clone()
+    keep = (ix * r_size <= crd[1]) & (crd[1] < (ix + 2) * r_size) & (iy * r_size <= crd[2]) & (crd[2] < (iy + 2) * r_size)
+    dat, crd = dat[keep], crd[:, keep]
+    crd[1] -= ix * r_size
+    crd[2] -= iy * r_size
+    crd2, ssz2 = sparse_repatch(crd, (ssz[0], 2 * r_size, 2 * r_size, ssz[-1]), r_size)
+    rna = torch.sparse_coo_tensor(crd2, dat, tuple(ssz2)).to_dense()
+    sl = (slice(None), slice(None), slice(ix * patch_size, (ix + 2) * patch_size), slice(iy * patch_size, (iy + 2) * patch_size))
+    x_p, n_p, m_p = patchify(x_t[sl], patch_size), patchify(noise[sl], patch_size), patchify(loss_mask[sl], patch_size)
+    tm = torch.tensor(sch.timestep_map, dtype=torch.long)[t]
+    pred, pred2 = unet_forward(W, cfg, x_p, tm, rna, 2, 2, want_pred2=True)
+    noise_shift = patchify(unpatchify(n_p, 2, 2)[:, :, halfp:-halfp, halfp:-halfp], patch_size)
+    f = (lambda d: d ** 2) if loss_type == "mse" else (lambda d: d.abs())
+    flat = lambda v: v.reshape(v.shape[0], -1).mean(1)
+    return flat(f(noise_shift - pred)).mean() + flat(f(n_p - pred2) * m_p).mean(), x_t

@@ -124,6 +124,63 @@ class SpacedDiffusionBeatGans:
         c.sqrt_one_minus_alpha_bar_prev = float(torch.sqrt(1 - ab_prev))
         return c
 
+    # ---- training objective, forward half ------------------------------------
+    def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """q(x_t | x_0) (base.py:141-158): table entries cast .float() and broadcast per image."""
+        a = torch.from_numpy(self.sqrt_alphas_cumprod).to(x_start.device)[t].float().reshape(-1, 1, 1, 1)
+        b = torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).to(x_start.device)[t].float().reshape(-1, 1, 1, 1)
+        return a * x_start + b * noise
+
+    def training_losses(self, model, x_start, r_start, imgs, t, pos, loss_mask, idx=None, patch_size=64,
+                        model_kwargs=None, noise=None, *, crop_index=None, loss_type: str = "mse"):
+        """GaussianDiffusionBeatGans.training_losses (base.py:181-289): diffuse the padded image, draw a random
+        2 x 2-patch window (`crop_index=(ix, iy)` pins the reference's two `random.randrange` draws), crop the COO
+        genes and the image to it, run the model once (P = 1: the four original patches -> `pred2`, the shifted
+        collage patch -> `pred`) and return {'loss', 'x_t'}: mse (or l1) of both predictions against the noise.
+        This is the FORWARD of the training step through the inference kernels -- the value a validation pass or a
+        loss curve needs; there is no backward (no gradient kernels), and the model runs as in `.eval()`
+        (the reference's ResBlock dropout p = 0.1, config_parm.py:46, is not applied)."""
+        import random
+        dev = x_start.device
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        halfp = patch_size // 2
+        t = t.to(dev).long()
+        t_cur = t.repeat_interleave(x_start.shape[0] // t.shape[0])                        # base.py:213-214
+        x_t = self.q_sample(x_start, t_cur, noise)
+        if loss_mask is not None:
+            x_t = x_t * loss_mask
+        terms = {"x_t": x_t}
+        if crop_index is None:
+            crop_index = (random.randrange(pos.shape[0] - 1), random.randrange(pos.shape[1] - 1))   # base.py:220-221
+        ix, iy = crop_index
+        dat, crd, ssz = r_start
+        r_size = patch_size // (x_start.shape[2] // ssz[1])
+        crd = crd.long()
+        keep = (ix * r_size <= crd[1]) & (crd[1] < (ix + 2) * r_size) & (iy * r_size <= crd[2]) & (crd[2] < (iy + 2) * r_size)
+        dat, crd = dat[keep], crd[:, keep].clone()
+        crd[1] -= ix * r_size
+        crd[2] -= iy * r_size
+        rna_pat = sparse_repatch((dat, crd, (ssz[0], 2 * r_size, 2 * r_size, ssz[-1])), r_size)
+        sl = (slice(None), slice(None), slice(ix * patch_size, (ix + 2) * patch_size),
+              slice(iy * patch_size, (iy + 2) * patch_size))
+
+        def tiles2(a):                                                                     # 'b c (p1 h) (p2 w) -> (b p1 p2) c h w'
+            b_, c_, H_, W_ = a.shape
+            return a.reshape(b_, c_, 2, patch_size, 2, patch_size).permute(0, 2, 4, 1, 3, 5).reshape(b_ * 4, c_, patch_size, patch_size)
+
+        x_p, n_p, m_p = tiles2(x_t[sl]), tiles2(noise[sl]), tiles2(loss_mask[sl])
+        tm = torch.tensor(self.timestep_map, dtype=torch.int64, device=dev)[t]            # _WrappedModel (diffusion.py:140-147)
+        shape_only = torch.empty((t.shape[0], x_start.shape[1], patch_size, patch_size), device="meta")   # do_train: p1 = p2 = 2
+        out = model(x=x_p, t=tm, rna=rna_pat, imgs=shape_only, patch_size=patch_size, want_pred2=True)
+        b_ = t.shape[0]
+        n_img = n_p.reshape(b_, 2, 2, -1, patch_size, patch_size).permute(0, 3, 1, 4, 2, 5).reshape(b_, -1, 2 * patch_size, 2 * patch_size)
+        noise_shift = n_img[:, :, halfp:-halfp, halfp:-halfp]                              # loss_mask given: the centre patch
+        f = (lambda d: d ** 2) if loss_type == "mse" else (lambda d: d.abs())
+        flat = lambda a: a.reshape(a.shape[0], -1).mean(1)
+        terms["loss"] = flat(f(noise_shift - out.pred)).mean() + flat(f(n_p - out.pred2) * m_p).mean()
+        return terms
+
     # ---- reference-shaped entry point ------------------------------------------------------------
     def sample(self, model, shape=None, noise=None, pos=None, cond=None, x_start=None, r_start=None, imgs=None,
                clip_denoised=True, idx=None, patch_size=64, model_kwargs=None, progress=False, *,

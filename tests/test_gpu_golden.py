@@ -111,3 +111,28 @@ def test_attention_driver_readout_vs_reference():
     assert out.dtype == torch.float16 and out.shape == (1, 50, 8, 16, 16)
     # fp16 storage: one ulp at |x| <= 4 is 2e-3; the softmax weights themselves agree to 1e-7
     assert (out[0].float().cpu() - gold).abs().max() <= 2e-3
+
+
+@pytest.mark.parametrize("name", ["mse_seed3", "l1_seed8"])
+def test_training_loss_forward_vs_reference(name):
+    """SpacedDiffusionBeatGans.training_losses (forward of the training step through the inference kernels) against the
+    value the reference's own training_losses returned on CPU (eval mode; oracle/make_train_golden.py)."""
+    import random
+
+    import train_cases as trc
+    gold = np.load(os.path.join(G, "train_loss.npz"))
+    seed, loss_type = trc.CASES[name]
+    x_pad, rna, imgs, t, pos, mask, idx, noise = trc.make_inputs(seed)
+    smp = SpacedDiffusionBeatGans(1000, "ddpm")
+    random.seed(seed)                                   # the reference's two random.randrange draws
+    terms = smp.training_losses(model(), x_pad.to(DEV), (rna[0].to(DEV), rna[1].to(DEV), rna[2]), imgs, t, pos, mask.to(DEV),
+                                idx=idx, patch_size=64, noise=noise.to(DEV), loss_type=loss_type)
+    ref = float(gold[f"{name}/loss"])
+    assert abs(float(terms["loss"]) - ref) < 2e-5 * ref, (float(terms["loss"]), ref)
+    st = gold[f"{name}/x_t_stats"]
+    assert abs(terms["x_t"].double().mean().item() - st[0]) < 1e-7
+    # pinned crop == the seeded draws
+    ix, iy = (int(v) for v in gold[f"{name}/crop"])
+    t2 = smp.training_losses(model(), x_pad.to(DEV), (rna[0].to(DEV), rna[1].to(DEV), rna[2]), imgs, t, pos, mask.to(DEV),
+                             idx=idx, patch_size=64, noise=noise.to(DEV), crop_index=(ix, iy), loss_type=loss_type)
+    assert float(t2["loss"]) == float(terms["loss"])

@@ -131,3 +131,24 @@ def test_oracle_vs_reference_other_configs(case):
     for name, got in (("pred", pred), ("pred2", pred2)):
         ref = gold[f"{cc.tag_of(case)}/{name}"]
         assert np.abs(cc.digest(got) - ref).max() < 5e-5, (case, name)
+
+
+# ---- training objective, forward half ---------------------------------------------
+def test_oracle_training_loss_vs_reference():
+    """oracle.training_losses against the loss the reference's own GaussianDiffusionBeatGans.training_losses
+    returned (eval mode, seeded crop, given noise; oracle/make_train_golden.py)."""
+    import train_cases as trc
+    from teramind_amd.weights import hashed_state_dict
+    gold = np.load(os.path.join(util.GOLDEN, "train_loss.npz"))
+    cfg = PathConfig()
+    sd = hashed_state_dict(cfg, 0)
+    sch = tc.make_schedule(1000, "ddpm")
+    torch.set_num_threads(8)
+    name, (seed, loss_type) = "mse_seed3", trc.CASES["mse_seed3"]
+    x_pad, rna, imgs, t, pos, mask, idx, noise = trc.make_inputs(seed)
+    ix, iy = (int(v) for v in gold[f"{name}/crop"])
+    with torch.inference_mode():
+        loss, x_t = tc.training_losses(sd, tc.oracle_config_from(cfg), sch, x_pad, rna, t, mask, noise, ix, iy, 64, loss_type)
+    assert abs(float(loss) - float(gold[f"{name}/loss"])) < 2e-5 * float(gold[f"{name}/loss"])
+    st = gold[f"{name}/x_t_stats"]
+    assert abs(x_t.double().mean().item() - st[0]) < 1e-7 and abs(x_t.double().abs().max().item() - st[1]) < 1e-6
