@@ -77,6 +77,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  teramind_amd has no CPU fallback.")
+        # torch first: it ships its own libamdhip64, and the library must bind to THAT runtime (the one that owns the
+        # tensors' device context) -- loaded the other way round the process ends up with two HIP runtimes and the
+        # library's hipMalloc reports "no ROCm-capable device"
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)       # AttributeError here = header/library mismatch
