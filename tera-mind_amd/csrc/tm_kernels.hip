@@ -38,15 +38,19 @@ struct C3Geo {
   static constexpr int WPIECES = WFLOATS / 4;
   static constexpr int PW = (WPIECES + 255) / 256;
   static constexpr int TAPS_TOTAL = (NZI == 1) ? 9 : 27;         // taps per channel block in the packed weights
-  static constexpr int LDS_BYTES = (WFLOATS + XV * 8) * 4;
+  // channel blocks per stage: the 9-tap in-plane form has half the MFMAs per block of the 18-tap z-skip form, so it
+  // stages two blocks per barrier pair to keep the same MFMA phase length
+  static constexpr int KB = (NZI == 1) ? 2 : 1;
+  static constexpr int LDS_BYTES = KB * (WFLOATS + XV * 8) * 4;
 };
 
 template <int NZI, int WM, int TW>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
   using G = C3Geo<NZI, WM, TW>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* lw = lds;
-  float* lx = lds + G::WFLOATS;
+  constexpr int KB = G::KB;
+  float* lw = lds;                                               // [KB][NTAP][512]
+  float* lx = lds + KB * G::WFLOATS;                             // [KB][XV][8]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -118,51 +122,63 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
 
-  f32x4 xr[G::PX], wr[G::PW];
+  f32x4 xr[KB][G::PX], wr[KB][G::PW];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto load_stage = [&](int cb) {
-    const float* xp = a.x + (long)cb * a.x_plane;
+  auto load_stage = [&](int st) {
 #pragma unroll
-    for (int k = 0; k < G::PX; ++k) xr[k] = (xoff[k] >= 0) ? *(const f32x4*)(xp + xoff[k]) : zero4;
-    const float* wp = wsrc + (long)cb * w_cb_stride;
+    for (int kb = 0; kb < KB; ++kb) {
+      const int cb = st * KB + kb;
+      const bool live = KB == 1 || cb < a.Cbi;                   // a missing second block contributes zeros
+      const float* xp = a.x + (long)cb * a.x_plane;
 #pragma unroll
-    for (int k = 0; k < G::PW; ++k)
-      if (G::WPIECES % 256 == 0 || tid + k * 256 < G::WPIECES) wr[k] = *(const f32x4*)(wp + k * 1024);
+      for (int k = 0; k < G::PX; ++k) xr[kb][k] = (live && xoff[k] >= 0) ? *(const f32x4*)(xp + xoff[k]) : zero4;
+      const float* wp = wsrc + (long)cb * w_cb_stride;
+#pragma unroll
+      for (int k = 0; k < G::PW; ++k)
+        if (G::WPIECES % 256 == 0 || tid + k * 256 < G::WPIECES) wr[kb][k] = live ? *(const f32x4*)(wp + k * 1024) : zero4;
+    }
   };
 
+  const int nst = (a.Cbi + KB - 1) / KB;
   load_stage(0);
-  for (int cb = 0; cb < a.Cbi; ++cb) {
+  for (int st = 0; st < nst; ++st) {
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < G::PX; ++k)
-      if (tid + k * 256 < G::XPIECES) *(f32x4*)(lx + (tid + k * 256) * 4) = xr[k];
+    for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-    for (int k = 0; k < G::PW; ++k)
-      if (G::WPIECES % 256 == 0 || tid + k * 256 < G::WPIECES) *(f32x4*)(lw + (tid + k * 256) * 4) = wr[k];
+      for (int k = 0; k < G::PX; ++k)
+        if (tid + k * 256 < G::XPIECES) *(f32x4*)(lx + kb * G::XV * 8 + (tid + k * 256) * 4) = xr[kb][k];
+#pragma unroll
+      for (int k = 0; k < G::PW; ++k)
+        if (G::WPIECES % 256 == 0 || tid + k * 256 < G::WPIECES) *(f32x4*)(lw + kb * G::WFLOATS + (tid + k * 256) * 4) = wr[kb][k];
+    }
     __syncthreads();
-    if (cb + 1 < a.Cbi) load_stage(cb + 1);
+    if (st + 1 < nst) load_stage(st + 1);
 
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int zi = 0; zi < NZI; ++zi) {
+    for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
+      for (int zi = 0; zi < NZI; ++zi) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tap = zi * 9 + ky * 3 + kx;
-          const int xd = ((zi * G::HR + ky) * G::HC + kx) * 8;
-          f32x4 wf[2], xf[WM];
-          wf[0] = *(const f32x4*)(lw + tap * 512 + wb);
-          wf[1] = *(const f32x4*)(lw + tap * 512 + 256 + wb);
+        for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-          for (int mt = 0; mt < WM; ++mt) xf[mt] = *(const f32x4*)(lx + xb[mt] + xd);
+          for (int kx = 0; kx < 3; ++kx) {
+            const int tap = zi * 9 + ky * 3 + kx;
+            const int xd = kb * G::XV * 8 + ((zi * G::HR + ky) * G::HC + kx) * 8;
+            f32x4 wf[2], xf[WM];
+            wf[0] = *(const f32x4*)(lw + kb * G::WFLOATS + tap * 512 + wb);
+            wf[1] = *(const f32x4*)(lw + kb * G::WFLOATS + tap * 512 + 256 + wb);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
+            for (int mt = 0; mt < WM; ++mt) xf[mt] = *(const f32x4*)(lx + xb[mt] + xd);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-              for (int mt = 0; mt < WM; ++mt)
-                acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][kk], xf[mt][kk], acc[ct][mt], 0, 0, 0);
+              for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+                  acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct][kk], xf[mt][kk], acc[ct][mt], 0, 0, 0);
+          }
         }
       }
     }
@@ -395,8 +411,12 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
       if (S >= 32) TM_LAUNCH3(2, 1, 32); else if (S == 16) TM_LAUNCH3(2, 1, 16); else TM_LAUNCH3(2, 1, 8);
     }
   } else if (nzi == 1) {
-    if (S >= 32) TM_LAUNCH3(1, 2, 32); else if (S == 16) TM_LAUNCH3(1, 2, 16); else if (S == 8) TM_LAUNCH3(1, 2, 8);
-    else TM_LAUNCH3(1, 1, 4);
+    if (S == 4) TM_LAUNCH3(1, 1, 4);
+    else if (variant == 2) {
+      if (S >= 32) TM_LAUNCH3(1, 2, 32); else if (S == 16) TM_LAUNCH3(1, 2, 16); else TM_LAUNCH3(1, 2, 8);
+    } else {                                   // small grids: 128-voxel workgroups fill more CUs
+      if (S >= 32) TM_LAUNCH3(1, 1, 32); else if (S == 16) TM_LAUNCH3(1, 1, 16); else TM_LAUNCH3(1, 1, 8);
+    }
   } else {
     if (S >= 32) TM_LAUNCH3(3, 2, 32); else if (S == 16) TM_LAUNCH3(3, 2, 16); else if (S == 8) TM_LAUNCH3(3, 2, 8);
     else TM_LAUNCH3(3, 1, 4);
