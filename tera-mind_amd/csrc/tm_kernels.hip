@@ -14,6 +14,7 @@
 //   (sampler_step / pad_patchify live in tm_sampler.hip: built with -ffp-contract=off)
 #include "tm_device.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace tmk {
@@ -418,8 +419,12 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
       if (S >= 32) TM_LAUNCH3(1, 1, 32); else if (S == 16) TM_LAUNCH3(1, 1, 16); else TM_LAUNCH3(1, 1, 8);
     }
   } else {
-    if (S >= 32) TM_LAUNCH3(3, 2, 32); else if (S == 16) TM_LAUNCH3(3, 2, 16); else if (S == 8) TM_LAUNCH3(3, 2, 8);
-    else TM_LAUNCH3(3, 1, 4);
+    if (S == 4) TM_LAUNCH3(3, 1, 4);
+    else if (variant == 2) {
+      if (S >= 32) TM_LAUNCH3(3, 2, 32); else if (S == 16) TM_LAUNCH3(3, 2, 16); else TM_LAUNCH3(3, 2, 8);
+    } else {
+      if (S >= 32) TM_LAUNCH3(3, 1, 32); else if (S == 16) TM_LAUNCH3(3, 1, 16); else TM_LAUNCH3(3, 1, 8);
+    }
   }
 #undef TM_LAUNCH3
   return hipGetLastError();
