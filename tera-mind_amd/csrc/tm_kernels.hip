@@ -1238,7 +1238,18 @@ __device__ __forceinline__ void gg_linear(const float* xs, int K, const float* _
     const float b = ok ? bias[c] : 0.f;
 #pragma unroll
     for (int r = 0; r < GG_RB; ++r) acc[r] = b;
-    for (int k = 0; k < K; ++k) {
+    // eight weight loads in flight per lane: the loop is latency-bound on the (L2-resident) weight column otherwise
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = ok ? W_t[(long)(k + u) * Nout + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int r = 0; r < GG_RB; ++r) acc[r] = fmaf(xs[r * K + k + u], w[u], acc[r]);
+    }
+    for (; k < K; ++k) {
       const float w = ok ? W_t[(long)k * Nout + c] : 0.f;
 #pragma unroll
       for (int r = 0; r < GG_RB; ++r) acc[r] = fmaf(xs[r * K + k], w, acc[r]);
@@ -1314,6 +1325,7 @@ __global__ __launch_bounds__(256) void gene_attn_generic_kernel(GeneGenArgs ga) 
     for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int r = 0; r < GG_RB; ++r) lg[j][r] = 0.f;
+#pragma unroll 2
     for (int d = 0; d < D; ++d) {
       const float* kr = qnT + (long)d * Gp + lane;
       float qv[GG_RB];
@@ -1839,6 +1851,7 @@ __global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int
       for (int r = 0; r < WQ; ++r) acc[r] = 0.f;
       if (ok) {
         const float* kp = kb + tokoff[u];
+#pragma unroll 4
         for (int cb = 0; cb < Cb; ++cb) {
           const f32x4 k0 = *(const f32x4*)(kp + (long)cb * a.plane), k1 = *(const f32x4*)(kp + (long)cb * a.plane + 4);
 #pragma unroll
@@ -1875,7 +1888,7 @@ __global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[r][j] = 0.f;
       const float* vp = vb + (long)cb * a.plane;
-#pragma unroll 2
+#pragma unroll 4
       for (int u = 0; u < T; ++u) {
         const f32x4 v0 = *(const f32x4*)(vp + tokoff[u]), v1 = *(const f32x4*)(vp + tokoff[u] + 4);
 #pragma unroll
