@@ -90,8 +90,9 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline); bf16 = config-4 arithmetic (bf16 3x3x3 convs)")
     ap.add_argument("--tile", action="store_true",
                     help="mode-B workload instead: one test_brn tile (25 z-chunks x 5x5 patches, P=4, DDIM) per step")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "conv27_traffic.json"),
-                    help="optional rocprofv3 --pmc derived HBM bytes per conv27_mfma launch")
+    ap.add_argument("--pmc-json", default=None,
+                    help="rocprofv3 --pmc derived HBM bytes per launch of the dominant conv kernel (default: "
+                         "profiles/conv27_traffic[_bf16][_tile].json for the selected workload)")
     args = ap.parse_args()
 
     import torch
@@ -177,9 +178,11 @@ def main():
         achieved = prof["nominal_flops"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] else 0.0
         traffic = None
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        if os.path.exists(args.pmc_json) and args.dtype == "f32" and not args.tile:
+        pmc_json = args.pmc_json or os.path.join(ROOT, "profiles", "conv27_traffic" + ("_bf16" if args.dtype == "bf16" else "") +
+                                                 ("_tile" if args.tile else "") + ".json")
+        if os.path.exists(pmc_json):
             try:
-                traffic = json.load(open(args.pmc_json)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc_json)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

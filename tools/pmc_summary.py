@@ -20,7 +20,11 @@ def load(path):
     return agg, {k: len(v) for k, v in calls.items()}
 
 
-def main(fetch_csv, write_csv, sq_csv=None, out_json=None):
+def main(fetch_csv, write_csv, sq_csv=None, out_json=None, prefix="conv3d_mfma<2,"):
+    """prefix: the dominant kernel whose launches are averaged into `hbm_bytes_per_launch` (bench.py's
+    `roofline.traffic`): 'conv3d_mfma<2,' for the fp32 path, 'conv27_bf16' for the bf16 path."""
+    if sq_csv in ("", "-"):
+        sq_csv = None
     f, nf = load(fetch_csv)
     w, _ = load(write_csv)
     sq, _ = load(sq_csv) if sq_csv else ({}, {})
@@ -38,12 +42,12 @@ def main(fetch_csv, write_csv, sq_csv=None, out_json=None):
     for r in rows:
         print(f"{r['kernel'][:28]:28s} {r['launches']:8d} {r['hbm_read_bytes_per_launch'] / 1e6:13.2f} "
               f"{r['hbm_write_bytes_per_launch'] / 1e6:13.2f} {r.get('mfma_busy_over_sq_busy', float('nan')):18.3f}")
-    conv = [r for r in rows if r["kernel"].startswith("conv3d_mfma<2,") or r["kernel"].startswith("conv27_mfma")]
+    conv = [r for r in rows if r["kernel"].startswith(prefix)]
     n = sum(r["launches"] for r in conv)
     tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in conv)
-    summary = {"kernel": "conv3d_mfma<2,*,*> (3x3x3 z-skip conv, all tile instantiations)", "launches": n, "hbm_bytes_per_launch": tot / max(1, n),
+    summary = {"kernel": prefix + "*> (3x3x3 conv, all tile instantiations)", "launches": n, "hbm_bytes_per_launch": tot / max(1, n),
                "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes", "per_kernel": rows}
-    print(f"conv3d_mfma<2,*,*>: {n} launches, {tot / max(1, n) / 1e6:.1f} MB HBM traffic per launch")
+    print(f"{prefix}*: {n} launches, {tot / max(1, n) / 1e6:.1f} MB HBM traffic per launch")
     if out_json:
         json.dump(summary, open(out_json, "w"), indent=1)
 
