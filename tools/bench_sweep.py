@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--init", choices=["reference", "device"], default="device")
     ap.add_argument("--state", choices=["fp32x2", "fp16"], default="fp32x2", help="TileSweep state layout (fp16 = whole-brain capable)")
+    ap.add_argument("--batch_tiles", type=int, default=1, help="tiles per model call (test_brn --batch_size)")
     args = ap.parse_args()
     import torch
     import teramind_amd  # noqa: F401
@@ -45,7 +46,7 @@ def main():
         return resident[(row, col)]
 
     sw = TileSweep(cfg, SpacedDiffusionBeatGans(args.T, "ddim"), model, genes, hst=256, wst=256, hnm=args.rows,
-                   wnm=args.cols, total_epochs=args.T, total_slc=50, device=dev, batch_tiles=1, init=args.init, state=args.state)
+                   wnm=args.cols, total_epochs=args.T, total_slc=50, device=dev, batch_tiles=args.batch_tiles, init=args.init, state=args.state)
     for r in range(args.rows):
         for c in range(args.cols):
             genes(1 + r, 1 + c)
@@ -59,7 +60,7 @@ def main():
     tiles = args.rows * args.cols
     per = dt / (args.steps * tiles)
     st = sw.local_state()
-    out = {"what": "TileSweep timed subset", "dtype": args.dtype, "state": args.state, "tiles": tiles, "steps_timed": args.steps,
+    out = {"what": "TileSweep timed subset", "dtype": args.dtype, "state": args.state, "batch_tiles": args.batch_tiles, "tiles": tiles, "steps_timed": args.steps,
            "z_chunks_per_tile": 25, "interior_patch_steps_per_tile_step": 400,
            "s_per_tile_step": round(per, 4), "interior_patch_steps_per_s": round(400 / per, 1),
            "state_finite": bool(torch.isfinite(st).all()), "state_absmax": float(st.abs().max()),
