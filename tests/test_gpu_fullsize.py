@@ -120,3 +120,25 @@ def test_bf16_against_fp32_at_full_size():
     rel = ((h - f).pow(2).mean().sqrt() / f.pow(2).mean().sqrt()).item()
     assert rel < 6e-3, rel
     _M.pop("bf16", None)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_ragged_batches_and_grids_are_per_image_independent(dtype):
+    """Odd batch sizes and non-square patch grids (ragged last workgroups in every kernel: patch counts that are not
+    multiples of the patches-per-workgroup, voxel counts that are not multiples of the tile): every image's result
+    inside the batch is bit-identical to the image run alone, in both arithmetic types."""
+    m = model(dtype)
+    for b, p1, p2 in ((3, 2, 5), (5, 2, 2), (2, 4, 3), (7, 3, 2)):
+        ne_img, nd_img = p1 * p2, (p1 - 1) * (p2 - 1)
+        x = synth.normal(f"rag/x{b}{p1}{p2}", (b * ne_img, 4, 64, 64), 3).to(DEV)
+        rna = synth.gene_counts(f"rag/r{b}{p1}{p2}", (b * ne_img, 4, 4, 2000), 3).to(DEV)
+        t = torch.tensor([(173 * (i + 1)) % 1000 for i in range(b)], dtype=torch.long, device=DEV)
+        big = m(x=x, t=t, rna=rna, imgs=torch.empty((b, 4, 64 * (p1 - 1), 64 * (p2 - 1)), device="meta"), patch_size=64,
+                want_pred2=True)
+        assert torch.isfinite(big.pred).all() and big.pred.shape[0] == b * nd_img
+        for i in (0, b - 1):
+            one = m(x=x[i * ne_img:(i + 1) * ne_img], t=t[i:i + 1], rna=rna[i * ne_img:(i + 1) * ne_img],
+                    imgs=torch.empty((1, 4, 64 * (p1 - 1), 64 * (p2 - 1)), device="meta"), patch_size=64, want_pred2=True)
+            assert torch.equal(one.pred, big.pred[i * nd_img:(i + 1) * nd_img]), (dtype, b, p1, p2, i)
+            assert torch.equal(one.pred2, big.pred2[i * ne_img:(i + 1) * ne_img]), (dtype, b, p1, p2, i)
+    _M.pop("bf16", None)
