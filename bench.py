@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="f32 = BASELINE configs[1] (the headline); bf16 = config-4 arithmetic (bf16 3x3x3 convs)")
     ap.add_argument("--tile", action="store_true",
                     help="mode-B workload instead: one test_brn tile (25 z-chunks x 5x5 patches, P=4, DDIM) per step")
@@ -178,7 +178,7 @@ def main():
         achieved = prof["nominal_flops"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] else 0.0
         traffic = None
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        pmc_json = args.pmc_json or os.path.join(ROOT, "profiles", "conv27_traffic" + ("_bf16" if args.dtype == "bf16" else "") +
+        pmc_json = args.pmc_json or os.path.join(ROOT, "profiles", "conv27_traffic" + ("_bf16" if args.dtype != "f32" else "") +
                                                  ("_tile" if args.tile else "") + ".json")
         if os.path.exists(pmc_json):
             try:
@@ -199,7 +199,7 @@ def main():
                        "per_gpu_patches_per_step": b * P * P, "parallelism": f"dp{world} (independent patch batches)"},
             "full_50_step_patches_per_s": round(value / T_STEPS, 4),
             "roofline": {"bound": "mfma", "kernel": ("conv3d_mfma<2,*,*> (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
-                                                      else "conv27_bf16 (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x16_bf16)"),
+                                                      else f"conv27_{args.dtype} (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x16_{args.dtype})"),
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "launches_timed": prof["launches"], "launches_per_step": prof["launches"] // max(1, args.steps),

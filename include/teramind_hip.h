@@ -40,8 +40,10 @@ enum {
 /* TM_DTYPE_F32: every kernel computes in fp32 (exact-fp32 MFMA).  TM_DTYPE_BF16: the 3x3x3 convs
  * (95 % of the FLOPs) take bf16 weights and bf16 normalised/activated inputs on the bf16 MFMA with
  * fp32 accumulation; the residual stream, norms, attention and everything else stay fp32.
+ * TM_DTYPE_F16: the same kernels with IEEE-half operands -- the arithmetic the reference runs on GPUs
+ * (autocast('cuda', fp16), diffusion/base.py:377): same speed as bf16, 3 more mantissa bits, fp16 range.
  * Parameters are always loaded as fp32 and rounded (RNE) when packed. */
-enum { TM_DTYPE_F32 = 0, TM_DTYPE_BF16 = 1 };
+enum { TM_DTYPE_F32 = 0, TM_DTYPE_BF16 = 1, TM_DTYPE_F16 = 2 };
 enum { TM_SAMPLE_DDPM = 0, TM_SAMPLE_DDIM = 1 };
 
 /* Model configuration.  Replaces BeatGANsUNetConfig as filled by
@@ -57,7 +59,7 @@ typedef struct tm_config {
   int32_t attn_res;       /* attention_resolutions[0]: 16 */
   int32_t num_res_blocks; /* 2 */
   int32_t vis_only;       /* 1: attention-map model (model/unet_attn.py), time_embed + rna_blocks[0] */
-  int32_t dtype;          /* TM_DTYPE_F32 | TM_DTYPE_BF16 (compute type of the 3x3x3 convs) */
+  int32_t dtype;          /* TM_DTYPE_F32 | TM_DTYPE_BF16 | TM_DTYPE_F16 (operand type of the convs / Linears / attention) */
 } tm_config;
 
 typedef struct tm_model tm_model;

@@ -38,8 +38,9 @@ class PathConfig:
     gen_type: str = "ddpm"              # 'ddpm' | 'ddim'
     fp16: bool = True                   # reference autocast flag (inert on CPU)
     batch_size: int = 1
-    # arithmetic type of the 3x3x3 convs: "f32" (exact-fp32 MFMA) or "bf16" (bf16 MFMA, fp32 accumulate;
-    # BASELINE config 4).  Not part of the checkpoint name.
+    # operand type of the convs / Linears / attention: "f32" (exact-fp32 MFMA), "bf16" (BASELINE config 4) or "f16"
+    # (IEEE half: the reference's own GPU arithmetic under autocast, config_parm.py:40); 16-bit modes accumulate in
+    # fp32.  Not part of the checkpoint name.
     compute_dtype: str = field(default="f32", compare=False)
     name: str = field(default="", compare=False)
 
@@ -48,7 +49,7 @@ class PathConfig:
             raise NotImplementedError("Patch size not in [32, 64, 128]")
         if self.rna_slc not in DOWN_Z_KERNEL:
             raise ValueError(f"rna_slc {self.rna_slc} not in {sorted(DOWN_Z_KERNEL)}")
-        if self.compute_dtype not in ("f32", "bf16"):
+        if self.compute_dtype not in ("f32", "bf16", "f16"):
             raise ValueError(f"compute_dtype {self.compute_dtype!r}")
         if self.stain not in ("DAPI", "PolyT", "all"):
             raise ValueError(f"stain {self.stain!r}")

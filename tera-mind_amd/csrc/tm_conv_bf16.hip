@@ -17,6 +17,27 @@
 //   * packed weights carry the 16-byte slot swap for couts with bit 3 set that makes the
 //     ds_read_b128 of the weight fragment bank-conflict free (cdna guide T2 / microarch LDS table).
 // Same operand orientation (weight = A, activation = B) and epilogue as conv3d_mfma.
+//
+// This translation unit is built TWICE (Makefile): as is for bf16, and with -DTM_H16_F16 for IEEE half (fp16) operands
+// -- the arithmetic the reference itself runs on GPUs (autocast('cuda', fp16), diffusion/base.py:377; config_parm.py:40).
+// The f16 MFMA forms take the same cycles as the bf16 ones; only the element type, the MFMA builtin, the host-side
+// rounding of the packed weights and the exported names (…_f16 instead of …_bf16) differ.
+#ifdef TM_H16_F16
+#define TM_H16_T _Float16
+#define TM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define conv27_bf16 conv27_f16
+#define conv1_bf16 conv1_f16
+#define window_attn_bf16 window_attn_f16
+#define fused_norm_epilogue fused_norm_epilogue_f16
+#define launch_conv27_bf16 launch_conv27_f16
+#define launch_conv1_bf16 launch_conv1_f16
+#define launch_window_attn_bf16 launch_window_attn_f16
+#define conv_bf16_pack_host conv_f16_pack_host
+#define conv1_bf16_pack_host conv1_f16_pack_host
+#else
+#define TM_H16_T __bf16
+#define TM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 #include "tm_device.h"
 
 #include <stdlib.h>
@@ -24,7 +45,8 @@
 
 namespace tmk {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef TM_H16_T h16_t;
+typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));      // 8 x 16-bit floats (bf16 or, with TM_H16_F16, fp16)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector (HIP's uint4 class resists SROA)
 
 struct ConvArgsH {
@@ -73,7 +95,7 @@ __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) ss[mt] += red[((wm * 4 + mt) * 2 + (wn ^ 1)) * 32 + i32];
   }
-  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  typedef h16_t bf16x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     if (ooff[mt] < 0) continue;
@@ -92,7 +114,7 @@ __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 
         for (int j = 0; j < 4; ++j) {
           float v = w4[j] * (acc[ct][mt][4 * g + j] * rstd);
           v = v * (1.0f + sc[j]) + sh[j];
-          ob[j] = (__bf16)silu_f(v);
+          ob[j] = (h16_t)silu_f(v);
         }
         *(bf16x4_t*)(ah.a2 + (long)on[mt] * ah.a2_nstride + (long)cob * a.y_plane + ooff[mt] + 4 * h) = ob;
         __builtin_amdgcn_sched_barrier(0);          // keep the per-(cout block) loads from being hoisted en masse
@@ -165,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   mt_ -= zo * tiles;
   const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
 
-  const __bf16* xg = (const __bf16*)a.x;
-  const __bf16* wg = (const __bf16*)a.w;
+  const h16_t* xg = (const h16_t*)a.x;
+  const h16_t* wg = (const h16_t*)a.w;
 
   // ---- staging descriptors: piece i = tid + k*512 lands in LDS slot WPIECES + i (lane-linear per wave,
   //      as the LDS-DMA requires); halo slots outside the plane / patch are never loaded and keep the
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
     xoff[k] = off;
   }
   // packed weights: [n-tile][pair][kz 3][9 taps][TN][2][8]
-  const __bf16* wsrc = wg + (long)nt * ah.Cbp * 27 * TN * 16 + (long)tid * 8;
+  const h16_t* wsrc = wg + (long)nt * ah.Cbp * 27 * TN * 16 + (long)tid * 8;
 
   // ---- fragment addresses (16-byte units inside a buffer) ----
   int xb[4], on[4], ooff[4];
@@ -227,11 +249,11 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   auto issue_stage = [&](int hs) {
     const int cbp = hs >> 1, zi = hs & 1;
     u32x4* base = lds16 + (hs & 1) * G::BUF16;
-    const __bf16* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
+    const h16_t* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
 #pragma unroll
     for (int k = 0; k < G::PW; ++k)
       if (G::WPIECES % 512 == 0 || k * 512 + wv * 64 < G::WPIECES) TM_GLDS16(wp + (long)k * 512 * 8, base + k * 512 + wv * 64);
-    const __bf16* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
+    const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
 #pragma unroll
     for (int k = 0; k < G::PX; ++k)
       if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * 512 + wv * 64);
@@ -267,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-          acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][ct], xf[cur][mt], acc[ct][mt], 0, 0, 0);
+          acc[ct][mt] = TM_MFMA16(wf[cur][ct], xf[cur][mt], acc[ct][mt]);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();          // drains this wave's LDS-DMA (vmcnt) and fences the buffer swap
@@ -315,9 +337,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   const int nt = bid % a.ntile;
   const int mtile = bid / a.ntile;
   const long VPN = (long)a.Z * a.S * a.S, vtot = VPN * a.N;
-  const __bf16* xg = (const __bf16*)a.x;
-  const __bf16* wg = (const __bf16*)a.w;
-  const __bf16* zp = (const __bf16*)zero_page;
+  const h16_t* xg = (const h16_t*)a.x;
+  const h16_t* wg = (const h16_t*)a.w;
+  const h16_t* zp = (const h16_t*)zero_page;
 
   long xoff[G::PX];
   int xkp[G::PX];
@@ -336,7 +358,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
     xoff[k] = off;
   }
   // packed weights: [n-tile][pair][TN][2][8]; piece i = tid + k*NT of a stage belongs to pair i / (TN*2)
-  const __bf16* wsrc = wg + (long)nt * ah.Cbp * TN * 16 + (long)tid * 8;
+  const h16_t* wsrc = wg + (long)nt * ah.Cbp * TN * 16 + (long)tid * 8;
 
   int xb[4], on[4], ooff[4];
 #pragma unroll
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-          acc[ct][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct], xf[mt], acc[ct][mt], 0, 0, 0);
+          acc[ct][mt] = TM_MFMA16(wf[ct], xf[mt], acc[ct][mt]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -452,7 +474,7 @@ struct WinArgsH {
 template <int T>
 __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   using G = WAGeo<T>;
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Pl = smem;                                   // [128][PP]
   unsigned char* Vt = Pl + G::P_BYTES;                        // 2 x [WPW][CH][PP]
@@ -475,13 +497,13 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   }
   for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
   __syncthreads();
-  const __bf16* qb = (const __bf16*)a.q + (long)n * a.q_ns;
-  const __bf16* kb = (const __bf16*)a.k + (long)n * a.k_ns;
-  const __bf16* vb = (const __bf16*)a.v + (long)n * a.v_ns;
+  const h16_t* qb = (const h16_t*)a.q + (long)n * a.q_ns;
+  const h16_t* kb = (const h16_t*)a.k + (long)n * a.k_ns;
+  const h16_t* vb = (const h16_t*)a.v + (long)n * a.v_ns;
   {  // RMSNorm statistics of the 128 query and 128 key tokens (fp32 sums over the bf16 values)
     const bool isq = tid < 128;
     const int t = tid & 127;
-    const __bf16* p = (isq ? qb : kb) + tokoff[t];
+    const h16_t* p = (isq ? qb : kb) + tokoff[t];
     float ss = 0.f;
     for (int cb = 0; cb < C / 8; ++cb) {
       const bf16x8 v8 = *(const bf16x8*)(p + (long)cb * a.plane);
@@ -501,8 +523,8 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   for (int ct = 0; ct < G::NW; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-  const __bf16* qp = qb + tokoff[qtok] + (long)h * a.plane;
-  const __bf16* kp[G::NW];
+  const h16_t* qp = qb + tokoff[qtok] + (long)h * a.plane;
+  const h16_t* kp[G::NW];
 #pragma unroll
   for (int ct = 0; ct < G::NW; ++ct) kp[ct] = kb + tokoff[wbase + ct * 32 + i32] + (long)h * a.plane;
   bf16x8 qn = *(const bf16x8*)qp, kn[G::NW];
@@ -513,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
     {
       const f32x4 wa = *(const f32x4*)(w2 + kp2 * 16 + 8 * h), wb = *(const f32x4*)(w2 + kp2 * 16 + 8 * h + 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { qf[j] = (__bf16)((float)qn[j] * wa[j]); qf[4 + j] = (__bf16)((float)qn[4 + j] * wb[j]); }
+      for (int j = 0; j < 4; ++j) { qf[j] = (h16_t)((float)qn[j] * wa[j]); qf[4 + j] = (h16_t)((float)qn[4 + j] * wb[j]); }
     }
     bf16x8 kf[G::NW];
 #pragma unroll
@@ -525,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
       for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)(kp[ct] + po);
     }
 #pragma unroll
-    for (int ct = 0; ct < G::NW; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ct], qf, acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < G::NW; ++ct) acc[ct] = TM_MFMA16(kf[ct], qf, acc[ct]);
   }
   // ---- scale + softmax over the keys of this lane's query (registers, then lane ^ 32) ----
   {
@@ -554,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
       for (int g = 0; g < 4; ++g) {
         bf16x4 pk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = (__bf16)(acc[ct][4 * g + j] * inv);
+        for (int j = 0; j < 4; ++j) pk[j] = (h16_t)(acc[ct][4 * g + j] * inv);
         *(bf16x4*)(prow + (ct * 32 + 8 * g + 4 * h) * 2) = pk;
       }
   }
@@ -562,8 +584,8 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   // V staging: 512 items per stage = 64 token pairs x 8 channel blocks; thread owns items tid and tid + 256
   const int gp = tid & 63;                                    // token pair (workgroup numbering 2gp, 2gp+1)
   const int swin = (2 * gp) / T, st = (2 * gp) % T;
-  const __bf16* vs0 = vb + tokoff[2 * gp];
-  const __bf16* vs1 = vb + tokoff[2 * gp + 1];
+  const h16_t* vs0 = vb + tokoff[2 * gp];
+  const h16_t* vs1 = vb + tokoff[2 * gp + 1];
   const int scb = tid >> 6;                                   // channel blocks scb and scb + 4 of the stage
   bf16x8 vr[4];
   auto vload = [&](int c0) {
@@ -577,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
     for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef h16_t bf16x2 __attribute__((ext_vector_type(2)));
         bf16x2 two;
         two[0] = vr[2 * half][j]; two[1] = vr[2 * half + 1][j];
         *(bf16x2*)(base + ((scb + 4 * half) * 8 + j) * G::PP) = two;
@@ -595,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   }
   const int myoff = tokoff[qtok];
   const int vwin = (T == 128) ? 0 : wv;
-  __bf16* ob = (__bf16*)a.o + (long)n * a.o_ns;
+  h16_t* ob = (h16_t*)a.o + (long)n * a.o_ns;
   int buf = 0;
   for (int c0 = 0; c0 < C; c0 += G::CH) {
     if (c0 + G::CH < C) vstore(buf ^ 1);                      // next stage's registers -> the other buffer
@@ -609,13 +631,13 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
       const unsigned char* ar = vrow + (long)(ctile * 32 + i32) * G::PP;
 #pragma unroll
       for (int kb2 = 0; kb2 < T / 16; ++kb2)
-        oc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ar + kb2 * 32), pf[kb2], oc, 0, 0, 0);
+        oc = TM_MFMA16(*(const bf16x8*)(ar + kb2 * 32), pf[kb2], oc);
       // lane = token qtok; accumulator quad g = channels c0 + 32*ctile + 8g + 4h .. +3
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 o4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j] = (__bf16)oc[4 * g + j];
+        for (int j = 0; j < 4; ++j) o4[j] = (h16_t)oc[4 * g + j];
         *(bf16x4*)(ob + myoff + (long)((c0 + 32 * ctile) / 8 + g) * a.plane + 4 * h) = o4;
       }
     }
@@ -650,6 +672,14 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
 }
 
 // ------------------------------------------------------------------------------------------
+#ifdef TM_H16_F16
+static inline uint16_t f32_to_bf16_rne(float f) {      // here: fp32 -> IEEE half, round to nearest even (saturating to inf like the cast)
+  const _Float16 hf = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &hf, 2);
+  return u;
+}
+#else
 static inline uint16_t f32_to_bf16_rne(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -657,14 +687,19 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+#endif
 
+#ifndef TM_H16_F16
 int conv_bf16_tn(int Cout) { return Cout <= 64 ? 64 : 128; }
+#endif
 
+#ifndef TM_H16_F16
 size_t conv_bf16_pack_elems(int Cout, int Cbi) {
   const int TN = conv_bf16_tn(Cout);
   const int ntile = (Cout + TN - 1) / TN, Cbp = (Cbi + 1) / 2;
   return (size_t)ntile * Cbp * 27 * TN * 16;
 }
+#endif
 
 void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out) {
   int Cin = 0, Cbi = 0;
@@ -689,10 +724,12 @@ void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, u
   }
 }
 
+#ifndef TM_H16_F16
 size_t conv1_bf16_pack_elems(int Cout, int Cbi) {
   const int TN = conv_bf16_tn(Cout);
   return (size_t)((Cout + TN - 1) / TN) * ((Cbi + 1) / 2) * TN * 16;
 }
+#endif
 void conv1_bf16_pack_host(const float* w /*[Cout][Cin]*/, int Cout, const int* seg_c, int nseg, uint16_t* out) {
   int Cin = 0, Cbi = 0;
   for (int s = 0; s < nseg; ++s) { Cin += seg_c[s]; Cbi += (seg_c[s] + 7) / 8; }

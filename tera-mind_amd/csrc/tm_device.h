@@ -9,6 +9,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TM_EPS 1e-6f
+#ifndef TM_H16_T
+#define TM_H16_T __bf16          // 16-bit float type of the y_h / gate_h tensors in this translation unit (tm_conv_bf16.hip)
+#endif
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -94,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
           const f32x4 gv = *(const f32x4*)(a.gate + (long)on[mt] * a.gate_nstride + pl);
           o *= gv;
         } else if (a.gate_h) {
-          typedef __bf16 bf16x4_g __attribute__((ext_vector_type(4)));
+          typedef TM_H16_T bf16x4_g __attribute__((ext_vector_type(4)));
           const bf16x4_g gb = *(const bf16x4_g*)(a.gate_h + (long)on[mt] * a.gate_h_nstride + pl);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] *= (float)gb[j];
@@ -104,10 +107,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
           o = rv + o;
         }
         if (a.y_h) {
-          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          typedef TM_H16_T bf16x4_t __attribute__((ext_vector_type(4)));
           bf16x4_t ob;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+          for (int j = 0; j < 4; ++j) ob[j] = (TM_H16_T)o[j];
           *(bf16x4_t*)(a.y_h + (long)on[mt] * a.yh_nstride + pl) = ob;
           continue;
         }

@@ -92,6 +92,13 @@ void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, u
 hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s);
 hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, const float* qnorm_w, const float* knorm_w,
                                    TVH o, hipStream_t s);
+// IEEE-half twins of the five functions above (tm_conv_bf16.hip built with -DTM_H16_F16): same layouts, fp16 elements
+void conv1_f16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
+hipError_t launch_conv1_f16(const ConvLaunchH& L, hipStream_t s);
+void conv_f16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
+hipError_t launch_conv27_f16(const ConvLaunchH& L, hipStream_t s);
+hipError_t launch_window_attn_f16(const TVH& q, const TVH& k, const TVH& v, const float* qnorm_w, const float* knorm_w,
+                                  TVH o, hipStream_t s);
 
 // ---- prep: concat + resample + RMSNorm(C) * w -> modulate -> act ---------------------
 struct PrepSrc {
@@ -127,6 +134,7 @@ struct PrepLaunch {
   int pad_blocks = 0;               // extra all-zero channel blocks appended to the bf16 output (pair padding)
   uint16_t* raw_h = nullptr;        // bf16 instead of `raw` (input of the bf16 skip conv); same pad_blocks
   long raw_h_nstride = 0;
+  int h_f16 = 0;                    // the 16-bit tensors (out_h, raw_h, mod_*_h) are IEEE half instead of bf16
 };
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
 

@@ -560,10 +560,17 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
     } else if (L.mod == MOD_VOXEL) {
       const long mo = (long)n * L.mod_stride + (long)gb * oplane + oin;
       if (L.mod_scale_h) {
-        typedef __bf16 bf16x8_m __attribute__((ext_vector_type(8)));
-        const bf16x8_m scb = *(const bf16x8_m*)(L.mod_scale_h + mo), shb = *(const bf16x8_m*)(L.mod_shift_h + mo);
+        if (L.h_f16) {
+          typedef _Float16 f16x8_m __attribute__((ext_vector_type(8)));
+          const f16x8_m scb = *(const f16x8_m*)(L.mod_scale_h + mo), shb = *(const f16x8_m*)(L.mod_shift_h + mo);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = (float)scb[j]; sh[j] = (float)shb[j]; }
+          for (int j = 0; j < 8; ++j) { sc[j] = (float)scb[j]; sh[j] = (float)shb[j]; }
+        } else {
+          typedef __bf16 bf16x8_m __attribute__((ext_vector_type(8)));
+          const bf16x8_m scb = *(const bf16x8_m*)(L.mod_scale_h + mo), shb = *(const bf16x8_m*)(L.mod_shift_h + mo);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { sc[j] = (float)scb[j]; sh[j] = (float)shb[j]; }
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = L.mod_scale[mo + j]; sh[j] = L.mod_shift[mo + j]; }
@@ -593,12 +600,20 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
       for (int j = 0; j < 8; ++j) { o[j] *= 0.25f; r[j] *= 0.25f; }
     }
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     const long eo = (long)gb * oplane + oin;
     if (L.out_h) {
-      bf16x8 ob;
+      if (L.h_f16) {
+        f16x8 ob;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ob[j] = (__bf16)o[j];
-      *(bf16x8*)(L.out_h + (long)n * L.out_h_nstride + eo) = ob;
+        for (int j = 0; j < 8; ++j) ob[j] = (_Float16)o[j];
+        *(f16x8*)(L.out_h + (long)n * L.out_h_nstride + eo) = ob;
+      } else {
+        bf16x8 ob;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ob[j] = (__bf16)o[j];
+        *(bf16x8*)(L.out_h + (long)n * L.out_h_nstride + eo) = ob;
+      }
     } else if (L.out) {
       float* op = L.out + (long)n * L.out_nstride + eo;
       *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
@@ -610,10 +625,17 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
       *(f32x4*)(rp + 4) = f32x4{r[4], r[5], r[6], r[7]};
     }
     if (L.raw_h) {
-      bf16x8 rb;
+      if (L.h_f16) {
+        f16x8 rb;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rb[j] = (__bf16)r[j];
-      *(bf16x8*)(L.raw_h + (long)n * L.raw_h_nstride + eo) = rb;
+        for (int j = 0; j < 8; ++j) rb[j] = (_Float16)r[j];
+        *(f16x8*)(L.raw_h + (long)n * L.raw_h_nstride + eo) = rb;
+      } else {
+        bf16x8 rb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = (__bf16)r[j];
+        *(bf16x8*)(L.raw_h + (long)n * L.raw_h_nstride + eo) = rb;
+      }
     }
   };
   if (CACHED) {

@@ -33,6 +33,7 @@ int tmk::io_fail(int code, const char* msg) { return fail(code, "%s", msg); }
   } while (0)
 
 static const int RNA_TAIL[3] = {128, 64, 32};          // model/unet_ours.py:278-279
+static inline bool is_h16(int dtype) { return dtype == TM_DTYPE_BF16 || dtype == TM_DTYPE_F16; }   // 16-bit operand modes
 
 // ------------------------------------------------------------------------------------------
 struct HostParam {
@@ -287,7 +288,7 @@ extern "C" const char* tm_last_error(void) { return g_err; }
 
 extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
   if (!cfg || !out) return fail(TM_ERR_ARG, "null argument");
-  if (cfg->dtype != TM_DTYPE_F32 && cfg->dtype != TM_DTYPE_BF16) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_F32 or TM_DTYPE_BF16");
+  if (cfg->dtype != TM_DTYPE_F32 && !is_h16(cfg->dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_F32, TM_DTYPE_BF16 or TM_DTYPE_F16");
   if (cfg->patch_size != 32 && cfg->patch_size != 64 && cfg->patch_size != 128)
     return fail(TM_ERR_ARG, "patch_size must be 32, 64 or 128 (config_parm.py:47-55), got %d", cfg->patch_size);
   if (cfg->rna_slc != 1 && cfg->rna_slc != 4 && cfg->rna_slc != 8 && cfg->rna_slc != 16)
@@ -299,8 +300,8 @@ extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
                 (cfg->patch_size / 16) * (cfg->patch_size / 16) * cfg->rna_slc);
   if (cfg->rna_num == 81 && cfg->rna_slc != 1)
     return fail(TM_ERR_ARG, "the 81-gene human-brain subset requires rna_slc = 1 (model/unet_ours.py:313-316)");
-  if (cfg->dtype == TM_DTYPE_BF16 && (cfg->patch_size != 64 || cfg->rna_slc != 4 || cfg->rna_num > 232))
-    return fail(TM_ERR_ARG, "TM_DTYPE_BF16 is implemented for the checkpoint geometry only (patch_size 64, rna_slc 4, rna_num <= 232)");
+  if (is_h16(cfg->dtype) && (cfg->patch_size != 64 || cfg->rna_slc != 4 || cfg->rna_num > 232))
+    return fail(TM_ERR_ARG, "TM_DTYPE_BF16 / TM_DTYPE_F16 are implemented for the checkpoint geometry only (patch_size 64, rna_slc 4, rna_num <= 232)");
   if (cfg->net_ch % 64 || cfg->embed_ch % 64 || cfg->embed_ch > 1024)
     return fail(TM_ERR_ARG, "net_ch must be a multiple of 64, embed_ch a multiple of 64 <= 1024");
   tm_model* m = new tm_model();
@@ -395,7 +396,8 @@ static void pack_conv_h(tm_model* m, Packer& pk, std::vector<Fix>& fx, std::vect
   cw.Cout = Cout; cw.Cbi = cbi; cw.taps = 27; cw.ntile = (Cout + 63) / 64; cw.w = nullptr;
   const size_t elems = conv_bf16_pack_elems(Cout, cbi);
   size_t off = pk.reserve((elems + 1) / 2);
-  conv_bf16_pack_host(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(), (uint16_t*)(pk.buf.data() + off));
+  (m->cfg.dtype == TM_DTYPE_F16 ? conv_f16_pack_host : conv_bf16_pack_host)(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(),
+                                                                            (uint16_t*)(pk.buf.data() + off));
   fxh.push_back({wslot, off});
   size_t boff = pk.reserve((size_t)cw.ntile * 64);
   const std::vector<float>& b = P(m, bkey);
@@ -439,7 +441,8 @@ static void pack_linear_stack_h(tm_model* m, Packer& pk, std::vector<Fix>& fx, s
   cw.Cout = Cout; cw.Cbi = cbi; cw.taps = 1; cw.ntile = (Cout + 63) / 64; cw.w = nullptr;
   const size_t elems = conv1_bf16_pack_elems(Cout, cbi);
   size_t off = pk.reserve((elems + 1) / 2);
-  conv1_bf16_pack_host(w.data(), Cout, seg.data(), (int)seg.size(), (uint16_t*)(pk.buf.data() + off));
+  (m->cfg.dtype == TM_DTYPE_F16 ? conv1_f16_pack_host : conv1_bf16_pack_host)(w.data(), Cout, seg.data(), (int)seg.size(),
+                                                                              (uint16_t*)(pk.buf.data() + off));
   fxh.push_back({wslot, off});
   size_t boff = pk.reserve((size_t)cw.ntile * 64);
   for (int i = 0; i < Cout; ++i) pk.buf[boff + i] = b[i];
@@ -488,7 +491,7 @@ extern "C" int tm_model_finalize(tm_model* m) {
   Packer pk;
   std::vector<Fix> fx;
   std::vector<FixH> fxh;
-  const bool bf16 = c.dtype == TM_DTYPE_BF16;
+  const bool bf16 = is_h16(c.dtype);            // 16-bit operand mode (bf16 or fp16): same packing layout
   pack_raw(pk, fx, &m->te_w1, P(m, "time_embed.time_embed.0.weight"));
   pack_raw(pk, fx, &m->te_b1, P(m, "time_embed.time_embed.0.bias"));
   pack_raw(pk, fx, &m->te_w2, P(m, "time_embed.time_embed.2.weight"));
@@ -733,7 +736,7 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
     }
     cx.check(hipEventRecord(m->prof_ev[m->prof_used].first, cx.s));
   }
-  cx.check(launch_conv27_bf16(L, cx.s));
+  cx.check(m->cfg.dtype == TM_DTYPE_F16 ? launch_conv27_f16(L, cx.s) : launch_conv27_bf16(L, cx.s));
   if (prof) {
     cx.check(hipEventRecord(m->prof_ev[m->prof_used].second, cx.s));
     m->prof_used++;
@@ -750,7 +753,7 @@ static void run_conv1_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& c
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
   L.gate_h = gate_h;
   if (y_h) { L.y_h = y_h->p; L.yh_nstride = y_h->nstride; }
-  cx.check(launch_conv1_bf16(L, cx.s));
+  cx.check(cx.m->cfg.dtype == TM_DTYPE_F16 ? launch_conv1_f16(L, cx.s) : launch_conv1_bf16(L, cx.s));
 }
 
 // ResBlock._forward (model/MBAblocks.py:237-299)
@@ -761,7 +764,8 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   TV out = out_opt ? *out_opt : cx.tensor(N, w.cout, Z, S_out);
   const size_t mark = cx.top;
   int cin_pad = w.cbi * 8;
-  const bool bf16 = m->cfg.dtype == TM_DTYPE_BF16;
+  const bool bf16 = is_h16(m->cfg.dtype);
+  const int h_f16 = m->cfg.dtype == TM_DTYPE_F16;
   TV A, raw, H1, A2;
   TVH Ah, A2h;
   if (bf16) Ah = cx.tensor_h(N, (w.cbi + 1) / 2 * 2, Z, S_out);
@@ -783,7 +787,7 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     }
     P.resample = mode; P.N = N; P.Z = Z; P.S = S_out; P.p1 = cx.p1; P.p2 = cx.p2;
     P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
-    if (bf16) { P.out_h = Ah.p; P.out_h_nstride = Ah.nstride; P.pad_blocks = Ah.Cb - w.cbi; }
+    if (bf16) { P.out_h = Ah.p; P.out_h_nstride = Ah.nstride; P.pad_blocks = Ah.Cb - w.cbi; P.h_f16 = h_f16; }
     else { P.out = A.p; P.out_nstride = A.nstride; }
     if (need_raw && raw_bf16) { P.raw_h = rawh.p; P.raw_h_nstride = rawh.nstride; }
     else if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
@@ -811,7 +815,7 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
     P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
     P.mod_stride = m->emb_tot;
-    if (bf16) { P.out_h = A2h.p; P.out_h_nstride = A2h.nstride; P.pad_blocks = A2h.Cb - w.cout / 8; }
+    if (bf16) { P.out_h = A2h.p; P.out_h_nstride = A2h.nstride; P.pad_blocks = A2h.Cb - w.cout / 8; P.h_f16 = h_f16; }
     else { P.out = A2.p; P.out_nstride = A2.nstride; }
     cx.check(launch_prep(P, cx.s));
   }
@@ -840,7 +844,8 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
 static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_image, const TV* cond_act = nullptr) {
   const size_t mark = cx.top;
   const int N = x.N, Z = x.Z, S = x.H, C = w.C, cb = C / 8;
-  if (cx.m->cfg.dtype == TM_DTYPE_BF16) {
+  if (is_h16(cx.m->cfg.dtype)) {
+    const int h_f16 = cx.m->cfg.dtype == TM_DTYPE_F16;
     // bf16 operands for every Linear (fp32 accumulate); the residual stream x, q/k/v and the softmax stay fp32.
     // Activations that only feed a Linear, and the 7C modulation tensor (shift/scale/gate/cross-cond chunks), are
     // produced directly in bf16: the cross-cond chunk is the kv Linear's input as it stands.
@@ -854,7 +859,7 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
       P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = act; P.per_image = per_image;
       P.norm_w = nw; P.inv_c = 1.0f / (float)Creal;
       if (sc) { P.mod = MOD_VOXEL; P.mod_scale_h = sc->p; P.mod_shift_h = sh->p; P.mod_stride = sc->nstride; }
-      P.out_h = dst.p; P.out_h_nstride = dst.nstride; P.pad_blocks = dst.Cb - Cbs;
+      P.out_h = dst.p; P.out_h_nstride = dst.nstride; P.pad_blocks = dst.Cb - Cbs; P.h_f16 = h_f16;
       cx.check(launch_prep(P, cx.s));
     };
     TVH cact = cx.tensor_h(N, gbe, Z, S);
@@ -874,7 +879,7 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     q_geom.nstride = (long)cb * x.plane();
     run_conv1_h(cx, xa, w.qh, w.q, q_geom, nullptr, nullptr, 0, &q);
     run_conv1_h(cx, crs, w.kvh, w.kv, kv_geom, nullptr, nullptr, 0, &kv);
-    if (!cx.dry) cx.check(launch_window_attn_bf16(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, oh, cx.s));
+    if (!cx.dry) cx.check((h_f16 ? launch_window_attn_f16 : launch_window_attn_bf16)(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, oh, cx.s));
     run_conv1_h(cx, oh, w.projh, w.proj, x, &x, nullptr, 0, nullptr, &g_a);
     prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
     TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);

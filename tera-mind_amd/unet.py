@@ -33,7 +33,7 @@ def _tm_config(cfg: PathConfig, vis_only: bool) -> _lib.TmConfig:
     for i, v in enumerate(cfg.ch_mult):
         c.ch_mult[i] = v
     c.num_res_blocks, c.vis_only = cfg.num_res_blocks, int(vis_only)
-    c.dtype = {"f32": 0, "bf16": 1}[cfg.compute_dtype]
+    c.dtype = {"f32": 0, "bf16": 1, "f16": 2}[cfg.compute_dtype]
     return c
 
 

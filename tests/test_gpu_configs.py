@@ -68,5 +68,6 @@ def test_attention_maps_500_genes():
 def test_unsupported_configs_fail_loudly():
     with pytest.raises(RuntimeError, match="gene-token width"):
         BeatGANsUNetModel(cc.path_config((128, 16, "all", 229)), DEV)
-    with pytest.raises(RuntimeError, match="BF16"):
-        BeatGANsUNetModel(cc.path_config((32, 4, "all", 229), compute_dtype="bf16"), DEV)
+    for dt in ("bf16", "f16"):
+        with pytest.raises(RuntimeError, match="BF16"):
+            BeatGANsUNetModel(cc.path_config((32, 4, "all", 229), compute_dtype=dt), DEV)

@@ -113,16 +113,17 @@ def test_tile_config_interior_patch_locality():
         assert d <= 1e-5, f"interior patch ({img},{i},{j}): P=4 vs P=1 differ by {d}"
 
 
-def test_bf16_against_fp32_at_full_size():
+@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-3), ("f16", 8e-4)])
+def test_bf16_against_fp32_at_full_size(dtype, tol):
     x_T, rna = _inputs(B, 1, "full")
     f = _run(x_T, rna, steps=1)[0]
-    h = _run(x_T, rna, steps=1, dtype="bf16")[0]
+    h = _run(x_T, rna, steps=1, dtype=dtype)[0]
     rel = ((h - f).pow(2).mean().sqrt() / f.pow(2).mean().sqrt()).item()
-    assert rel < 6e-3, rel
-    _M.pop("bf16", None)
+    assert rel < tol, rel
+    _M.pop(dtype, None)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_ragged_batches_and_grids_are_per_image_independent(dtype):
     """Odd batch sizes and non-square patch grids (ragged last workgroups in every kernel: patch counts that are not
     multiples of the patches-per-workgroup, voxel counts that are not multiples of the tile): every image's result
@@ -141,4 +142,5 @@ def test_ragged_batches_and_grids_are_per_image_independent(dtype):
                     imgs=torch.empty((1, 4, 64 * (p1 - 1), 64 * (p2 - 1)), device="meta"), patch_size=64, want_pred2=True)
             assert torch.equal(one.pred, big.pred[i * nd_img:(i + 1) * nd_img]), (dtype, b, p1, p2, i)
             assert torch.equal(one.pred2, big.pred2[i * ne_img:(i + 1) * ne_img]), (dtype, b, p1, p2, i)
-    _M.pop("bf16", None)
+    if dtype != "f32":
+        _M.pop(dtype, None)
