@@ -14,7 +14,7 @@ All inputs are resident in HBM before the timed region.  The unit is the interio
 shards by independent patches: weak scaling, no data-path collective); the only collectives
 are the one-off RCCL broadcast of rank 0's packed weight arena and the timing barrier.
 
-Prints ONE JSON line on rank 0, with `roofline` (dominant kernel conv27_mfma: nominal dense-conv
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, the 3x3x3 implicit-GEMM conv: nominal dense-conv
 FLOPs per launch / average launch duration from hipEvents recorded on the launch stream during
 the timed region, against the fp32 MFMA peak) and `cpu_baseline` (oracle/teramind_cpu.py on the
 host cores, bounded sample).

@@ -162,7 +162,7 @@ int tm_gene_tile_dense(const int32_t* crd, const void* dat, int64_t nnz, int gbl
 int tm_blosc_decompress(const void* src, size_t src_bytes, void* dst, size_t dst_cap, size_t* out_bytes);
 
 /* Measurement hooks (bench.py): while enabled, every launch of the dominant kernel
- * (conv27_mfma, the 3x3x3 implicit-GEMM conv) inside tm_unet_forward is bracketed by two
+ * (conv3d_mfma<2,..> in fp32, conv27_bf16 / conv27_f16 in the 16-bit modes: the 3x3x3 implicit-GEMM conv) inside tm_unet_forward is bracketed by two
  * hipEvents recorded on the forward's stream.  tm_profile_collect synchronises on the last
  * event, adds up the bracketed durations and the per-launch work, and resets the counters.
  *   nominal_flops  = 2*Cin*Cout*27*voxels per launch (dense-conv convention; what

@@ -100,7 +100,7 @@ class _HipModel(torch.nn.Module):
         return torch.as_tensor(holder, device=self.device)
 
     def profile(self, on: bool):
-        """Bracket every conv27_mfma launch with hipEvents (measurement hook, bench.py)."""
+        """Bracket every 3x3x3 conv launch (the dominant kernel) with hipEvents (measurement hook, bench.py)."""
         _lib.check(self._L.tm_profile_enable(self._h, int(on)), "tm_profile_enable")
 
     def profile_collect(self) -> dict:
