@@ -181,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;                        // n-tile of TN couts
   int mt_ = bid / a.ntile;
-  const int pg = mt_ / (2 * tiles);
-  mt_ -= pg * 2 * tiles;
+  const int pg = mt_ / (a.Z * tiles);                  // a.Z output (= input) planes, pad 1 in z
+  mt_ -= pg * a.Z * tiles;
   const int zo = mt_ / tiles;
   mt_ -= zo * tiles;
   const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
@@ -245,9 +245,13 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   }
   __syncthreads();
 
-  // one stage = (channel-block pair, input plane zi): global -> LDS by LDS-DMA, no staging registers
+  // one stage = (channel-block pair, input plane zi): global -> LDS by LDS-DMA, no staging registers.  Output plane zo
+  // reads the input planes [zo-1, zo+1] that exist (kz = zi + 1 - zo): 2 of 3 for the z_size-2 checkpoint model, 1 for
+  // z_size 1, 2 or 3 for z_size 4 / 8 -- planes in the zero padding are never staged nor multiplied
+  const int zi0 = zo > 0 ? zo - 1 : 0;
+  const int npl = (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;
   auto issue_stage = [&](int hs) {
-    const int cbp = hs >> 1, zi = hs & 1;
+    const int cbp = hs / npl, zi = zi0 + hs % npl;
     u32x4* base = lds16 + (hs & 1) * G::BUF16;
     const h16_t* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
       if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * 512 + wv * 64);
   };
 
-  const int NH = 2 * ah.Cbp;
+  const int NH = npl * ah.Cbp;
   issue_stage(0);
   __syncthreads();
   for (int hs = 0; hs < NH; ++hs) {
@@ -817,19 +821,19 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.y = L.y.p; a.y_nstride = L.y.nstride; a.y_plane = L.y.plane(); a.Cob = L.y.Cb;
   a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
   a.gate = nullptr; a.gate_nstride = 0;
-  a.N = L.x.N; a.S = L.x.H; a.Z = 2; a.Cbi = L.x.Cb; a.flags = 0;
+  a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = 0;
   a.y_h = nullptr; a.yh_nstride = 0;
   ah.fuse = L.fuse_norm; ah.norm_w = L.norm_w; ah.mod_scale = L.mod_scale; ah.mod_shift = L.mod_shift;
   ah.mod_stride = L.mod_stride; ah.per_image = L.per_image; ah.inv_c = 1.0f / (float)L.Cout;
   ah.a2 = L.a2.p; ah.a2_nstride = L.a2.nstride;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
-  if (L.x.Cb & 1 || L.x.Z != 2 || L.y.Z != 2 || L.x.H != L.x.W || L.y.H != L.x.H || L.y.N != L.x.N)
+  if (L.x.Cb & 1 || L.x.Z < 1 || L.y.Z != L.x.Z || L.x.H != L.x.W || L.y.H != L.x.H || L.y.N != L.x.N)
     return hipErrorInvalidValue;
   const int S = a.S, TN = conv_bf16_tn(L.Cout);
   a.ntile = (L.Cout + TN - 1) / TN;
   if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
   if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res)) return hipErrorInvalidValue;
-  if (S != 8 && S != 16 && S != 32 && S != 64) return hipErrorInvalidValue;
+  if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
   do {                                                                                          \
     using G = HGeo<TN_, TW_>;                                                                   \
@@ -844,7 +848,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     }                                                                                           \
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
-    const long grid = pgs * 2 * tiles * a.ntile;                                                \
+    const long grid = pgs * a.Z * tiles * a.ntile;                                              \
     if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<TN_, TW_, true>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
     else hipLaunchKernelGGL((conv27_bf16<TN_, TW_, false>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
   } while (0)

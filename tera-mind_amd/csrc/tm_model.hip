@@ -300,8 +300,8 @@ extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
                 (cfg->patch_size / 16) * (cfg->patch_size / 16) * cfg->rna_slc);
   if (cfg->rna_num == 81 && cfg->rna_slc != 1)
     return fail(TM_ERR_ARG, "the 81-gene human-brain subset requires rna_slc = 1 (model/unet_ours.py:313-316)");
-  if (is_h16(cfg->dtype) && (cfg->patch_size != 64 || cfg->rna_slc != 4 || cfg->rna_num > 232))
-    return fail(TM_ERR_ARG, "TM_DTYPE_BF16 / TM_DTYPE_F16 are implemented for the checkpoint geometry only (patch_size 64, rna_slc 4, rna_num <= 232)");
+  if (is_h16(cfg->dtype) && cfg->patch_size == 32)
+    return fail(TM_ERR_ARG, "TM_DTYPE_BF16 / TM_DTYPE_F16 need patch_size 64 or 128 (no 4 x 4 tile form of the 16-bit conv)");
   if (cfg->net_ch % 64 || cfg->embed_ch % 64 || cfg->embed_ch > 1024)
     return fail(TM_ERR_ARG, "net_ch must be a multiple of 64, embed_ch a multiple of 64 <= 1024");
   tm_model* m = new tm_model();
@@ -618,7 +618,9 @@ extern "C" int tm_profile_collect(tm_model* m, tm_prof_stats* out) {
   out->launches = m->prof_used;
   out->nominal_flops = m->prof_nominal;
   // Z == 2: the z-skip form issues 18 of 27 taps; Z == 1: the centre slice only (9); Z >= 3: all 27 (zero planes staged)
-  out->executed_flops = m->prof_nominal * (m->z == 2 ? 18.0 / 27.0 : (m->z == 1 ? 9.0 / 27.0 : 1.0));
+  // (the 16-bit conv never stages z-padding planes: (3Z - 2) / 3Z of the taps for any Z)
+  out->executed_flops = m->prof_nominal * (is_h16(m->cfg.dtype) ? (3.0 * m->z - 2.0) / (3.0 * m->z)
+                                                                 : (m->z == 2 ? 18.0 / 27.0 : (m->z == 1 ? 9.0 / 27.0 : 1.0)));
   out->alg_bytes = m->prof_bytes;
   m->prof_used = 0; m->prof_nominal = 0; m->prof_bytes = 0;
   return TM_OK;
@@ -872,14 +874,25 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     TVH crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
     TVH xa = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
     prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
-    // q, k, v leave their Linears as bf16 (the attention core's MFMA operands); softmax and accumulation are fp32
-    TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, S);
-    TV q_geom = x; q_geom.p = nullptr;
-    TV kv_geom = x; kv_geom.Cb = 2 * cb; kv_geom.C = 2 * C; kv_geom.p = nullptr; kv_geom.nstride = (long)2 * cb * x.plane();
-    q_geom.nstride = (long)cb * x.plane();
-    run_conv1_h(cx, xa, w.qh, w.q, q_geom, nullptr, nullptr, 0, &q);
-    run_conv1_h(cx, crs, w.kvh, w.kv, kv_geom, nullptr, nullptr, 0, &kv);
-    if (!cx.dry) cx.check((h_f16 ? launch_window_attn_f16 : launch_window_attn_bf16)(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, oh, cx.s));
+    const int Tw = Z * (S / 2) * (S / 2);
+    if (Tw == 128 || Tw == 32) {
+      // q, k, v leave their Linears as 16-bit (the attention core's MFMA operands); softmax and accumulation are fp32
+      TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, S);
+      TV q_geom = x; q_geom.p = nullptr;
+      TV kv_geom = x; kv_geom.Cb = 2 * cb; kv_geom.C = 2 * C; kv_geom.p = nullptr; kv_geom.nstride = (long)2 * cb * x.plane();
+      q_geom.nstride = (long)cb * x.plane();
+      run_conv1_h(cx, xa, w.qh, w.q, q_geom, nullptr, nullptr, 0, &q);
+      run_conv1_h(cx, crs, w.kvh, w.kv, kv_geom, nullptr, nullptr, 0, &kv);
+      if (!cx.dry) cx.check((h_f16 ? launch_window_attn_f16 : launch_window_attn_bf16)(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, oh, cx.s));
+    } else {
+      // other window sizes (z_size 1 / 4 / 8, patch_size 128): fp32 q / k / v into the generic fp32 attention core, its
+      // output rounded to the 16-bit type for proj
+      TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, S), o = cx.tensor(N, C, Z, S);
+      run_conv1_h(cx, xa, w.qh, w.q, q, nullptr, nullptr, 0);
+      run_conv1_h(cx, crs, w.kvh, w.kv, kv, nullptr, nullptr, 0);
+      if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, o, cx.s));
+      prep_h(o.p, o.nstride, o.Cb, false, nullptr, nullptr, nullptr, 0, oh, C);
+    }
     run_conv1_h(cx, oh, w.projh, w.proj, x, &x, nullptr, 0, nullptr, &g_a);
     prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
     TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);

@@ -65,9 +65,30 @@ def test_attention_maps_500_genes():
     assert torch.equal(mid.cpu(), rm)
 
 
+@pytest.mark.parametrize("dtype,rel_tol", [("bf16", 7e-3), ("f16", 9e-4)])
+@pytest.mark.parametrize("case", [(64, 1, "all", 229), (64, 8, "all", 229), (128, 4, "DAPI", 229), (64, 16, "all", 229),
+                                  (64, 4, "all", 500), (64, 1, "all", 81)], ids=cc.tag_of)
+def test_unet_other_configs_16bit_modes(case, dtype, rel_tol):
+    """The 16-bit operand modes on the other z sizes (the 16-bit conv stages only the input planes that exist: 1, 2 or 3
+    per output plane), patch_size 128 and the generic gene / window attention fall-backs: relative L2 vs the fp32 oracle
+    within the operand-rounding bound of the type."""
+    cfg = cc.path_config(case, compute_dtype=dtype)
+    sd = hashed_state_dict(cfg, 0)
+    x, rna, t = cc.inputs(cfg)
+    torch.set_num_threads(16)
+    with torch.inference_mode():
+        ref, ref2 = tc.unet_forward(sd, tc.oracle_config_from(cfg), x, t, rna, 2, 2, want_pred2=True)
+    m = BeatGANsUNetModel(cfg, DEV).load_state_dict(sd)
+    out = m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, cfg.in_channels, cfg.patch_size, cfg.patch_size),
+            patch_size=cfg.patch_size, want_pred2=True)
+    for got, want in ((out.pred.cpu(), ref), (out.pred2.cpu(), ref2)):
+        rel = ((got - want).norm() / want.norm()).item()
+        assert rel < rel_tol, (case, dtype, rel)
+
+
 def test_unsupported_configs_fail_loudly():
     with pytest.raises(RuntimeError, match="gene-token width"):
         BeatGANsUNetModel(cc.path_config((128, 16, "all", 229)), DEV)
     for dt in ("bf16", "f16"):
-        with pytest.raises(RuntimeError, match="BF16"):
+        with pytest.raises(RuntimeError, match="patch_size 64 or 128"):
             BeatGANsUNetModel(cc.path_config((32, 4, "all", 229), compute_dtype=dt), DEV)
