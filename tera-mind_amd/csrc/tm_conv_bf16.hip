@@ -453,8 +453,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
 //   O^T = V^T.P^T: A = V^T (rows = channels) from an LDS image transposed while staging, 64 channels per
 //        stage, double buffered.  A lane ends up with one token and 4 consecutive channels per accumulator quad:
 //        the coalesced bf16 CB8 store of the conv epilogues.
-// T = 128: one workgroup per window, wave w owns queries [32w, 32w+32).  T = 32: one workgroup per patch, one
-// window per wave.  Either way a workgroup covers 128 query and 128 key tokens.
+// T = 128: one workgroup per window, wave w owns queries [32w, 32w+32).  T = 64: two windows per workgroup, two waves
+// each.  T = 32: one workgroup per patch, one window per wave.  A workgroup always covers 128 query and 128 key tokens.
 template <int T>
 struct WAGeo {
   static constexpr int NW = T / 32;                 // waves per window
@@ -488,10 +488,11 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   float* w2 = rk + 128;                                       // [C] q_norm.w * k_norm.w
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
-  const int n = (T == 128) ? (blockIdx.x >> 2) : blockIdx.x;
+  constexpr int NWG = 4 / G::WPW;                            // workgroups per patch (each covers WPW windows = 128 tokens)
+  const int n = blockIdx.x / NWG;
   const int S = a.S, hs = S / 2, C = a.C, npair = C / 16;
   if (tid < 128) {
-    const int win = (T == 128) ? (blockIdx.x & 3) : (tid / T);
+    const int win = (blockIdx.x % NWG) * G::WPW + tid / T;
     const int t = tid % T;
     const int wy = win >> 1, wx = win & 1;
     const int z = t / (hs * hs);
@@ -519,8 +520,8 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   }
   __syncthreads();
 
-  const int wbase = (T == 128) ? 0 : wv * T;                  // first token (workgroup numbering) of this wave's window
-  const int qtok = (T == 128) ? wv * 32 + i32 : wbase + i32;  // this lane's query
+  const int wbase = (wv / G::NW) * T;                         // first token (workgroup numbering) of this wave's window
+  const int qtok = wv * 32 + i32;                             // this lane's query (= wbase + 32 * (wv % NW) + i32)
   // ---- S^T = K.Q^T ----
   f32x16 acc[G::NW];
 #pragma unroll
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
     for (int kb2 = 0; kb2 < T / 16; ++kb2) pf[kb2] = *(const bf16x8*)(prow + kb2 * 32);
   }
   const int myoff = tokoff[qtok];
-  const int vwin = (T == 128) ? 0 : wv;
+  const int vwin = wv / G::NW;
   h16_t* ob = (h16_t*)a.o + (long)n * a.o_ns;
   int buf = 0;
   for (int c0 = 0; c0 < C; c0 += G::CH) {
@@ -657,7 +658,7 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
   a.qw = qnorm_w; a.kw = knorm_w; a.o = o.p; a.o_ns = o.nstride;
   a.C = q.Cb * 8; a.S = q.H; a.plane = (long)q.Z * q.H * q.W * 8;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
-  if (a.C % 64 || a.C > 512 || q.H != q.W || (q.H & 1) || (T != 128 && T != 32)) return hipErrorInvalidValue;
+  if (a.C % 64 || a.C > 512 || q.H != q.W || (q.H & 1) || (T != 128 && T != 64 && T != 32)) return hipErrorInvalidValue;
 #define TM_LAUNCHWA(T_)                                                                                     \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \
@@ -667,10 +668,10 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
       if (e != hipSuccess) return e;                                                                        \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL(window_attn_bf16<T_>, dim3((unsigned)(q.N * WAGeo<T_>::NW)), dim3(256),              \
+    hipLaunchKernelGGL(window_attn_bf16<T_>, dim3((unsigned)(q.N * (4 / WAGeo<T_>::WPW))), dim3(256),       \
                        WAGeo<T_>::LDS_BYTES, s, a);                                                         \
   } while (0)
-  if (T == 128) TM_LAUNCHWA(128); else TM_LAUNCHWA(32);
+  if (T == 128) TM_LAUNCHWA(128); else if (T == 64) TM_LAUNCHWA(64); else TM_LAUNCHWA(32);
 #undef TM_LAUNCHWA
   return hipGetLastError();
 }

@@ -875,7 +875,7 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     TVH xa = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
     prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
     const int Tw = Z * (S / 2) * (S / 2);
-    if (Tw == 128 || Tw == 32) {
+    if (Tw == 128 || Tw == 64 || Tw == 32) {
       // q, k, v leave their Linears as 16-bit (the attention core's MFMA operands); softmax and accumulation are fp32
       TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, S);
       TV q_geom = x; q_geom.p = nullptr;
@@ -1283,7 +1283,7 @@ extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const voi
 extern "C" int tm_op_window_attn(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_dev,
                                  const void* kw_dev, void* out, int N, int C, int Z, int S, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (C % 128) return fail(TM_ERR_ARG, "C must be a multiple of 128");
+  if (C % 64) return fail(TM_ERR_ARG, "C must be a multiple of 64");
   TV q = view_cb8(const_cast<void*>(q_cb8), N, C, Z, S, S), k = view_cb8(const_cast<void*>(k_cb8), N, C, Z, S, S);
   TV v = view_cb8(const_cast<void*>(v_cb8), N, C, Z, S, S);
   if (dtype == TM_DTYPE_F32) {

@@ -176,10 +176,12 @@ def _window_attn_ref(q, k, v, qw, kw):
     return o.reshape(N, Cc, Z, S, S)
 
 
-@pytest.mark.parametrize("C_,S,dtype", [(256, 16, "f32"), (512, 8, "f32"), (256, 16, "bf16"), (512, 8, "bf16"),
-                                        (128, 16, "bf16")])
-def test_window_attention_core(C_, S, dtype):
-    N, Z = 5, 2
+@pytest.mark.parametrize("C_,S,Z,dtype", [(256, 16, 2, "f32"), (512, 8, 2, "f32"), (256, 16, 2, "bf16"), (512, 8, 2, "bf16"),
+                                          (128, 16, 2, "bf16"), (256, 16, 1, "bf16"), (512, 8, 4, "bf16"),      # T = 64
+                                          (256, 16, 1, "f32"), (256, 16, 4, "f32"), (256, 16, 8, "f32"), (512, 4, 2, "f32"),
+                                          (512, 8, 1, "f32")])                                               # generic: T = 64, 256, 512, 8, 16
+def test_window_attention_core(C_, S, Z, dtype):
+    N = 3
     g = torch.Generator().manual_seed(C_ + S)
     q, k, v = (torch.randn((N, C_, Z, S, S), generator=g) * s for s in (1.5, 0.7, 1.0))
     qw, kw = torch.rand(C_, generator=g) + 0.5, torch.rand(C_, generator=g) + 0.5
