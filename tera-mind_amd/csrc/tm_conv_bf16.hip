@@ -28,6 +28,7 @@
 #define conv27_bf16 conv27_f16
 #define conv1_bf16 conv1_f16
 #define window_attn_bf16 window_attn_f16
+#define window_attn_long window_attn_long_f16
 #define fused_norm_epilogue fused_norm_epilogue_f16
 #define launch_conv27_bf16 launch_conv27_f16
 #define launch_conv1_bf16 launch_conv1_f16
@@ -651,6 +652,196 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   }
 }
 
+
+// ---- long windows (T = 256 / 512: the z_size 4 / 8 models at the resolution-16 attention blocks) --------------------
+// Same operand scheme as window_attn_bf16, but the keys are walked in blocks of 128 with an exact two-pass softmax:
+// pass 1 accumulates every query's running max / sum over all key blocks (S^T = K.Q^T only), pass 2 recomputes each
+// block's logits, writes P = exp(s - m) / l for that block to LDS and adds V_blk^T.P_blk^T into the output accumulators
+// (C / 32 tiles per wave, kept across key blocks).  One workgroup = 128 queries of one window; C <= 256.
+template <int T>
+struct WLGeo {
+  static constexpr int QBN = T / 128;                // query blocks (workgroups) per window
+  static constexpr int KBN = T / 128;                // key blocks
+  static constexpr int PP = 128 * 2 + 16;            // row pitch (bytes) of the P block and of a V^T row
+  static constexpr int P_BYTES = 128 * PP, VT_BYTES = 64 * PP;
+  static constexpr int LDS_BYTES = P_BYTES + VT_BYTES + (T /*tokoff*/ + 128 /*rq*/ + T /*rk*/ + 256 /*w2*/) * 4;
+};
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void window_attn_long(WinArgsH a) {
+  using G = WLGeo<T>;
+  typedef h16_t bf16x4 __attribute__((ext_vector_type(4)));
+  typedef h16_t bf16x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Pl = smem;                                   // [128 queries][128 keys of the current block]
+  unsigned char* Vt = Pl + G::P_BYTES;                        // [64 channels][128 keys]
+  int* tokoff = (int*)(Vt + G::VT_BYTES);                     // [T]
+  float* rq = (float*)(tokoff + T);                           // [128]
+  float* rk = rq + 128;                                       // [T]
+  float* w2 = rk + T;                                         // [C]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int qblk = blockIdx.x % G::QBN, win = (blockIdx.x / G::QBN) & 3, n = blockIdx.x / (4 * G::QBN);
+  const int wy = win >> 1, wx = win & 1;
+  const int S = a.S, hs = S / 2, C = a.C, npair = C / 16;
+  for (int t = tid; t < T; t += 256) {
+    const int z = t / (hs * hs);
+    const int r = t - z * hs * hs;
+    const int yl = r / hs, xl = r - yl * hs;
+    tokoff[t] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
+  __syncthreads();
+  const h16_t* qb = (const h16_t*)a.q + (long)n * a.q_ns;
+  const h16_t* kb = (const h16_t*)a.k + (long)n * a.k_ns;
+  const h16_t* vb = (const h16_t*)a.v + (long)n * a.v_ns;
+  for (int i = tid; i < 128 + T; i += 256) {                  // RMSNorm statistics: this block's queries, all keys
+    const bool isq = i < 128;
+    const int t = isq ? qblk * 128 + i : i - 128;
+    const h16_t* p = (isq ? qb : kb) + tokoff[t];
+    float ss = 0.f;
+    for (int cb = 0; cb < C / 8; ++cb) {
+      const bf16x8 v8 = *(const bf16x8*)(p + (long)cb * a.plane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)v8[j]; ss += f * f; }
+    }
+    const float r = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+    if (isq) rq[i] = r; else rk[t] = r;
+  }
+  __syncthreads();
+
+  const int qloc = wv * 32 + i32;                             // this lane's query inside the block
+  const int qoff = tokoff[qblk * 128 + qloc];
+  const float sq = rq[qloc] / (float)C;                       // (q*scale).(k*scale), scale = C^-1/2
+  const h16_t* qp = qb + qoff + (long)h * a.plane;
+  f32x16 acc[4];
+  // logits of key block kblk against this wave's 32 queries: acc[ct][r] = s(key kblk*128 + ct*32 + row(r, h), query i32)
+  auto s_block = [&](int kblk) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const h16_t* kp[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) kp[ct] = kb + tokoff[kblk * 128 + ct * 32 + i32] + (long)h * a.plane;
+    bf16x8 qn = *(const bf16x8*)qp, kn[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const bf16x8*)kp[ct];
+    for (int kp2 = 0; kp2 < npair; ++kp2) {
+      bf16x8 qf, kf[4];
+      const f32x4 wa = *(const f32x4*)(w2 + kp2 * 16 + 8 * h), wb = *(const f32x4*)(w2 + kp2 * 16 + 8 * h + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qf[j] = (h16_t)((float)qn[j] * wa[j]); qf[4 + j] = (h16_t)((float)qn[4 + j] * wb[j]); }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) kf[ct] = kn[ct];
+      if (kp2 + 1 < npair) {
+        const long po = (long)(kp2 + 1) * 2 * a.plane;
+        qn = *(const bf16x8*)(qp + po);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const bf16x8*)(kp[ct] + po);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = TM_MFMA16(kf[ct], qf, acc[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] *= sq * rk[kblk * 128 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+  };
+  // ---- pass 1: running max / sum of this lane's query over all keys ----
+  float m = -INFINITY, l = 0.f;
+  for (int kblk = 0; kblk < G::KBN; ++kblk) {
+    s_block(kblk);
+    float bm = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, acc[ct][r]);
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    float bs = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bs += expf(acc[ct][r] - mn);
+    bs += __shfl_xor(bs, 32, 64);
+    l = l * expf(m - mn) + bs;
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  // ---- pass 2: P block by block, O^T += V_blk^T . P_blk^T ----
+  f32x16 oc[8];
+#pragma unroll
+  for (int tI = 0; tI < 8; ++tI)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oc[tI][r] = 0.f;
+  const int gp = tid & 63, scb = tid >> 6;                    // V staging: token pair gp, channel blocks scb and scb + 4
+  for (int kblk = 0; kblk < G::KBN; ++kblk) {
+    s_block(kblk);
+    unsigned char* prow = Pl + (long)qloc * G::PP;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = (h16_t)(expf(acc[ct][4 * g + j] - m) * inv);
+        *(bf16x4*)(prow + (ct * 32 + 8 * g + 4 * h) * 2) = pk;
+      }
+    const h16_t* vs0 = vb + tokoff[kblk * 128 + 2 * gp];
+    const h16_t* vs1 = vb + tokoff[kblk * 128 + 2 * gp + 1];
+    bf16x8 pf[8];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      __syncthreads();                                        // V^T buffer free; (first time) every wave's P rows written
+      {
+        const long o0 = (long)(c0 / 8 + scb) * a.plane, o1 = o0 + 4 * a.plane;
+        const bf16x8 v00 = *(const bf16x8*)(vs0 + o0), v01 = *(const bf16x8*)(vs1 + o0);
+        const bf16x8 v10 = *(const bf16x8*)(vs0 + o1), v11 = *(const bf16x8*)(vs1 + o1);
+        unsigned char* base = Vt + gp * 4;                    // two keys = 4 bytes
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16x2 t0, t1;
+          t0[0] = v00[j]; t0[1] = v01[j]; t1[0] = v10[j]; t1[1] = v11[j];
+          *(bf16x2*)(base + (scb * 8 + j) * G::PP) = t0;
+          *(bf16x2*)(base + ((scb + 4) * 8 + j) * G::PP) = t1;
+        }
+      }
+      __syncthreads();
+      if (c0 == 0) {
+        const unsigned char* pr = Pl + (long)qloc * G::PP + 16 * h;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 8; ++kb2) pf[kb2] = *(const bf16x8*)(pr + kb2 * 32);
+      }
+      const unsigned char* vrow = Vt + 16 * h;
+#pragma unroll
+      for (int ctile = 0; ctile < 2; ++ctile) {
+        const unsigned char* ar = vrow + (long)(ctile * 32 + i32) * G::PP;
+        const int tI = c0 / 32 + ctile;
+        // static register indexing: the c0 loop has at most 4 iterations (C <= 256)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (cc == tI) {
+#pragma unroll
+            for (int kb2 = 0; kb2 < 8; ++kb2) oc[cc] = TM_MFMA16(*(const bf16x8*)(ar + kb2 * 32), pf[kb2], oc[cc]);
+          }
+      }
+    }
+    __syncthreads();                                          // P block consumed before the next block overwrites it
+  }
+  h16_t* ob = (h16_t*)a.o + (long)n * a.o_ns;
+#pragma unroll
+  for (int tI = 0; tI < 8; ++tI) {
+    if (tI * 32 >= C) break;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = (h16_t)oc[tI][4 * g + j];
+      *(bf16x4*)(ob + qoff + (long)(tI * 4 + g) * a.plane + 4 * h) = o4;
+    }
+  }
+}
+
 hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, const float* qnorm_w, const float* knorm_w,
                                    TVH o, hipStream_t s) {
   WinArgsH a;
@@ -658,7 +849,26 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
   a.qw = qnorm_w; a.kw = knorm_w; a.o = o.p; a.o_ns = o.nstride;
   a.C = q.Cb * 8; a.S = q.H; a.plane = (long)q.Z * q.H * q.W * 8;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
-  if (a.C % 64 || a.C > 512 || q.H != q.W || (q.H & 1) || (T != 128 && T != 64 && T != 32)) return hipErrorInvalidValue;
+  if (a.C % 64 || a.C > 512 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
+  if (T == 256 || T == 512) {
+    if (a.C > 256) return hipErrorInvalidValue;
+#define TM_LAUNCHWL(T_)                                                                                     \
+  do {                                                                                                      \
+    static bool attr_set = false;                                                                           \
+    if (!attr_set) {                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)window_attn_long<T_>,                                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, WLGeo<T_>::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                                        \
+      attr_set = true;                                                                                      \
+    }                                                                                                       \
+    hipLaunchKernelGGL(window_attn_long<T_>, dim3((unsigned)(q.N * 4 * WLGeo<T_>::QBN)), dim3(256),         \
+                       WLGeo<T_>::LDS_BYTES, s, a);                                                         \
+  } while (0)
+    if (T == 256) TM_LAUNCHWL(256); else TM_LAUNCHWL(512);
+#undef TM_LAUNCHWL
+    return hipGetLastError();
+  }
+  if (T != 128 && T != 64 && T != 32) return hipErrorInvalidValue;
 #define TM_LAUNCHWA(T_)                                                                                     \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \

@@ -875,7 +875,7 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     TVH xa = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
     prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
     const int Tw = Z * (S / 2) * (S / 2);
-    if (Tw == 128 || Tw == 64 || Tw == 32) {
+    if (Tw == 128 || Tw == 64 || Tw == 32 || ((Tw == 256 || Tw == 512) && C <= 256)) {
       // q, k, v leave their Linears as 16-bit (the attention core's MFMA operands); softmax and accumulation are fp32
       TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, S);
       TV q_geom = x; q_geom.p = nullptr;

@@ -178,6 +178,7 @@ def _window_attn_ref(q, k, v, qw, kw):
 
 @pytest.mark.parametrize("C_,S,Z,dtype", [(256, 16, 2, "f32"), (512, 8, 2, "f32"), (256, 16, 2, "bf16"), (512, 8, 2, "bf16"),
                                           (128, 16, 2, "bf16"), (256, 16, 1, "bf16"), (512, 8, 4, "bf16"),      # T = 64
+                                          (256, 16, 4, "bf16"), (256, 16, 8, "bf16"), (128, 16, 8, "bf16"),     # T = 256, 512 (two-pass)
                                           (256, 16, 1, "f32"), (256, 16, 4, "f32"), (256, 16, 8, "f32"), (512, 4, 2, "f32"),
                                           (512, 8, 1, "f32")])                                               # generic: T = 64, 256, 512, 8, 16
 def test_window_attention_core(C_, S, Z, dtype):
