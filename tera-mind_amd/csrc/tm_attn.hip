@@ -865,6 +865,172 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
 }
 
 
+
+// ---- fp32 MFMA form for long windows (T = 256 / 512: z_size 4 / 8 at the resolution-16 attention blocks) ----------------
+// One workgroup = 128 queries of one window; the keys are walked in blocks of 128 with an exact two-pass softmax
+// (pass 1: every query's max / sum over all keys; pass 2: per block P = exp(s - m) / l into LDS, O^T += V_blk^T.P_blk^T).
+// S^T = K.Q^T on v_mfma_f32_32x32x2_f32 (A = K: rows = keys, B = Q with q_norm.w * k_norm.w folded in), so a lane owns
+// one query: the softmax reductions are in-lane plus one exchange with lane ^ 32.  C <= 256.
+struct WinLongLds {
+  static constexpr int PS = 132;                 // row pitch (floats) of the P block and of a V^T row
+};
+
+template <int T>
+__global__ __launch_bounds__(256) void window_attn_mfma_long_kernel(WinArgs a) {
+  constexpr int PS = WinLongLds::PS, KBN = T / 128, QBN = T / 128;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* P = sm;                       // [128 queries][PS]
+  float* Vt = P + 128 * PS;            // [32 channels][PS]
+  float* rq = Vt + 32 * PS;            // [128]
+  float* rk = rq + 128;                // [T]
+  int* tokoff = (int*)(rk + T);        // [T]
+  float* w2 = (float*)(tokoff + T);    // [C]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int qblk = blockIdx.x % QBN, win = (blockIdx.x / QBN) & 3, n = blockIdx.x / (4 * QBN);
+  const int wy = win >> 1, wx = win & 1;
+  const int S = a.S, hs = S / 2, C = a.C, Cb = C / 8;
+  for (int t = tid; t < T; t += 256) {
+    const int z = t / (hs * hs);
+    const int r = t - z * hs * hs;
+    const int yl = r / hs, xl = r - yl * hs;
+    tokoff[t] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
+  __syncthreads();
+  const float* qb = a.q + (long)n * a.q_ns;
+  const float* kb = a.k + (long)n * a.k_ns;
+  const float* vb = a.v + (long)n * a.v_ns;
+  for (int i = tid; i < 128 + T; i += 256) {
+    const bool isq = i < 128;
+    const int t = isq ? qblk * 128 + i : i - 128;
+    const float* p = (isq ? qb : kb) + tokoff[t];
+    float ss = 0.f;
+    for (int cb = 0; cb < Cb; ++cb) {
+      const f32x4 a0 = *(const f32x4*)(p + (long)cb * a.plane), a1 = *(const f32x4*)(p + (long)cb * a.plane + 4);
+      ss += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] + a1[0] * a1[0] + a1[1] * a1[1] +
+            a1[2] * a1[2] + a1[3] * a1[3];
+    }
+    const float r = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+    if (isq) rq[i] = r; else rk[t] = r;
+  }
+  __syncthreads();
+
+  const int qloc = wv * 32 + i32;
+  const int qoff = tokoff[qblk * 128 + qloc];
+  const float sq = rq[qloc] / (float)C;                  // (q*scale).(k*scale), scale = C^-1/2 (MBAblocks.py:571-577)
+  const float* qp = qb + qoff + 4 * h;
+  f32x16 acc[4];
+  auto s_block = [&](int kblk) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const float* kp[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) kp[ct] = kb + tokoff[kblk * 128 + ct * 32 + i32] + 4 * h;
+    f32x4 qn = *(const f32x4*)qp, kn[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const f32x4*)kp[ct];
+    for (int cb = 0; cb < Cb; ++cb) {
+      const f32x4 qf = qn * *(const f32x4*)(w2 + cb * 8 + 4 * h);
+      f32x4 kf[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) kf[ct] = kn[ct];
+      if (cb + 1 < Cb) {
+        const long po = (long)(cb + 1) * a.plane;
+        qn = *(const f32x4*)(qp + po);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const f32x4*)(kp[ct] + po);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[ct][kk], qf[kk], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] *= sq * rk[kblk * 128 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+  };
+  float m = -INFINITY, l = 0.f;
+  for (int kblk = 0; kblk < KBN; ++kblk) {
+    s_block(kblk);
+    float bm = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bm = fmaxf(bm, acc[ct][r]);
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    float bs = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bs += expf(acc[ct][r] - mn);
+    bs += __shfl_xor(bs, 32, 64);
+    l = l * expf(m - mn) + bs;
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  f32x16 oc[8];
+#pragma unroll
+  for (int tI = 0; tI < 8; ++tI)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oc[tI][r] = 0.f;
+  const int su = tid & 127, scb = tid >> 7;              // V staging: key su of the block, channel blocks scb and scb + 2
+  for (int kblk = 0; kblk < KBN; ++kblk) {
+    s_block(kblk);
+    float* prow = P + qloc * PS;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = expf(acc[ct][4 * g + j] - m) * inv;
+        *(f32x4*)(prow + ct * 32 + 8 * g + 4 * h) = pk;
+      }
+    const float* vsrc = vb + tokoff[kblk * 128 + su] + (long)scb * a.plane;
+    const float* pfrag = P + qloc * PS + 4 * h;          // B operand: P[query][key0 + 4h ..]
+    const float* vfrag = Vt + i32 * PS + 4 * h;          // A operand: Vt[channel][key0 + 4h ..]
+    for (int c0 = 0; c0 < C; c0 += 32) {
+      __syncthreads();                                   // V^T free; (first time) the P rows are complete
+      {
+        const float* p0 = vsrc + (long)(c0 / 8) * a.plane;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const f32x4 v0 = *(const f32x4*)(p0 + (long)(2 * half) * a.plane), v1 = *(const f32x4*)(p0 + (long)(2 * half) * a.plane + 4);
+          float* d = Vt + ((scb + 2 * half) * 8) * PS + su;
+          d[0 * PS] = v0[0]; d[1 * PS] = v0[1]; d[2 * PS] = v0[2]; d[3 * PS] = v0[3];
+          d[4 * PS] = v1[0]; d[5 * PS] = v1[1]; d[6 * PS] = v1[2]; d[7 * PS] = v1[3];
+        }
+      }
+      __syncthreads();
+      const int tI = c0 / 32;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc)
+        if (cc == tI) {
+#pragma unroll 4
+          for (int u0 = 0; u0 < 128; u0 += 8) {
+            const f32x4 af = *(const f32x4*)(vfrag + u0), bf = *(const f32x4*)(pfrag + u0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) oc[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], oc[cc], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();                                     // P block consumed before the next block overwrites it
+  }
+#pragma unroll
+  for (int tI = 0; tI < 8; ++tI) {
+    if (tI * 32 >= C) break;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(f32x4*)(a.o + (long)n * a.o_ns + qoff + (long)(tI * 4 + g) * a.plane + 4 * h) =
+          f32x4{oc[tI][4 * g + 0], oc[tI][4 * g + 1], oc[tI][4 * g + 2], oc[tI][4 * g + 3]};
+  }
+}
+
 // ---- generic windowed attention core: any window size T = Z*(S/2)^2 <= 512, C <= 512 (fp32, VALU) ------------------
 // The other patch_size / rna_slc configurations (T = 8 ... 512).  One workgroup per (patch, window); a wave works on
 // WQ queries at a time so that every K / V fragment it loads feeds WQ dot products / accumulations: lanes = keys for the
@@ -1009,6 +1175,23 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
   a.C = q.Cb * 8; a.Z = q.Z; a.S = q.H; a.plane = q.plane();
   if (a.C % 8 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
+  if ((T == 256 || T == 512) && a.C <= 256 && !o_h) {   // long windows: key-blocked fp32 MFMA form
+    const size_t lds = ((size_t)(128 + 32) * WinLongLds::PS + 128 + 2 * T + a.C) * sizeof(float);
+#define TM_LAUNCHWL(T_)                                                                                              \
+  do {                                                                                                               \
+    static bool lattr = false;                                                                                       \
+    if (!lattr) {                                                                                                    \
+      hipError_t e = hipFuncSetAttribute((const void*)window_attn_mfma_long_kernel<T_>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      if (e != hipSuccess) return e;                                                                                 \
+      lattr = true;                                                                                                  \
+    }                                                                                                                \
+    hipLaunchKernelGGL(window_attn_mfma_long_kernel<T_>, dim3(q.N * 4 * (T_ / 128)), dim3(256), lds, s, a);          \
+  } while (0)
+    if (T == 256) TM_LAUNCHWL(256); else TM_LAUNCHWL(512);
+#undef TM_LAUNCHWL
+    return hipGetLastError();
+  }
   if ((T != 128 && T != 32) || a.C % 128) {            // the other configurations: generic kernel (fp32 output only)
     if (T > 512 || a.C > 512 || o_h) return hipErrorInvalidValue;
     const size_t lds = ((size_t)3 * T + a.C + 4 * WQ * (a.C + T)) * sizeof(float);
