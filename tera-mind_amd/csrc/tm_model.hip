@@ -96,7 +96,7 @@ struct tm_model {
   GeneW gene;
   ConvW downz, pyr[3];
   DirectW stem, head, downz_d;       // downz_d: direct-conv form of down_z when the MFMA form does not apply
-  bool downz_mfma = true;            // kz == 3 on a 4 x 4 gene grid (the checkpoint config)
+  bool downz_mfma = true;            // kz == 3 on a 4 x 4 (checkpoint config) or 8 x 8 gene grid
   bool gene_mfma = true;             // D == 64, G <= 232, no gene index table: fused MFMA gene-attention kernel
   const int* gene_idx = nullptr;     // device table: gene g reads slot gene_idx[g] (81-gene M2H subset) or null
   const float* out_norm = nullptr;
@@ -310,7 +310,7 @@ extern "C" int tm_model_create(const tm_config* cfg, tm_model** out) {
   m->gn = cfg->patch_size / 16;
   m->D = m->gn * m->gn * cfg->rna_slc;
   m->gene_mfma = m->D == 64 && cfg->rna_num <= 232 && cfg->rna_num != 81;
-  m->downz_mfma = cfg->rna_slc == 4 && m->gn == 4;
+  m->downz_mfma = cfg->rna_slc == 4 && (m->gn == 4 || m->gn == 8);   // kz == 3 on a grid the MFMA tile forms cover
   m->rw[0] = cfg->rna_num;
   for (int i = 0; i < 3; ++i) m->rw[i + 1] = RNA_TAIL[i];
   int rc = build_graph(m);
