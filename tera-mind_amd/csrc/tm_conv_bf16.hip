@@ -130,10 +130,12 @@ __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 
 //   TW = 32: column i -> (row, i): G1 and G2 each cover 16 distinct residues of one row (natural map);
 //   TW = 16: G1 -> row 0, G2 -> row 1 of the 2-row MFMA tile;
 //   TW =  8: pitch 12, G1 -> rows 0 and 2, G2 -> rows 1 and 3 of the 4-row MFMA tile.
-template <int TN, int TW>
+template <int TN, int TW, int NWV = 8>
 struct HGeo {
+  static constexpr int NT = NWV * 64;                 // threads: 8 waves (128 x 512 / 64 x 1024 tile) or 4 (half the voxels:
+                                                      // twice the workgroups for launches that would leave CUs idle)
   static constexpr int WNW = TN / 64;                 // waves along cout
-  static constexpr int WMW = 8 / WNW;                 // waves along voxels
+  static constexpr int WMW = NWV / WNW;               // waves along voxels
   static constexpr int TM = WMW * 128;                // voxels per workgroup
   static constexpr int TR = (TM / TW < TW) ? (TM / TW) : TW;
   static constexpr int NPB = TM / (TR * TW);
@@ -142,9 +144,9 @@ struct HGeo {
   static constexpr int XS = NPB * HR * HCP;           // slots of ONE k-half of ONE input plane
   static constexpr int XSP = (XS + 63) / 64 * 64;     // k-half arrays start on a wave's 64-slot boundary (LDS-DMA)
   static constexpr int XPIECES = XSP * 2;             // piece i -> LDS slot WPIECES + i
-  static constexpr int PX = (XPIECES + 511) / 512;
+  static constexpr int PX = (XPIECES + NT - 1) / NT;
   static constexpr int WPIECES = 9 * TN * 2;
-  static constexpr int PW = (WPIECES + 511) / 512;
+  static constexpr int PW = (WPIECES + NT - 1) / NT;
   static constexpr int BUF16 = WPIECES + 2 * XSP;     // 16-byte units per LDS buffer
   static constexpr int LDS_BYTES = 2 * BUF16 * 16;
 };
@@ -165,9 +167,10 @@ __device__ __forceinline__ void col_to_vox(int T, int i32, int& ps, int& r, int&
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int TN, int TW, bool FUSE>
-__global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
-  using G = HGeo<TN, TW>;
+template <int TN, int TW, bool FUSE, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
+  using G = HGeo<TN, TW, NWV>;
+  constexpr int NT = G::NT;
   const ConvArgs& a = ah.c;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
 
@@ -191,13 +194,13 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
   const h16_t* xg = (const h16_t*)a.x;
   const h16_t* wg = (const h16_t*)a.w;
 
-  // ---- staging descriptors: piece i = tid + k*512 lands in LDS slot WPIECES + i (lane-linear per wave,
+  // ---- staging descriptors: piece i = tid + k*NT lands in LDS slot WPIECES + i (lane-linear per wave,
   //      as the LDS-DMA requires); halo slots outside the plane / patch are never loaded and keep the
   //      zeros written once below ----
   long xoff[G::PX];
 #pragma unroll
   for (int k = 0; k < G::PX; ++k) {
-    const int i = tid + k * 512;
+    const int i = tid + k * NT;
     long off = -1;
     if (i < G::XPIECES) {
       const int half = i / G::XSP;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
       for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
 
   // zero both activation images once (conv zero padding + slots past the tile)
-  for (int i = tid; i < G::XPIECES; i += 512) {
+  for (int i = tid; i < G::XPIECES; i += NT) {
     lds16[G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
     lds16[G::BUF16 + G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
   }
@@ -257,11 +260,11 @@ __global__ __launch_bounds__(512, 2) void conv27_bf16(ConvArgsH ah) {
     const h16_t* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
 #pragma unroll
     for (int k = 0; k < G::PW; ++k)
-      if (G::WPIECES % 512 == 0 || k * 512 + wv * 64 < G::WPIECES) TM_GLDS16(wp + (long)k * 512 * 8, base + k * 512 + wv * 64);
+      if (G::WPIECES % NT == 0 || k * NT + wv * 64 < G::WPIECES) TM_GLDS16(wp + (long)k * NT * 8, base + k * NT + wv * 64);
     const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
 #pragma unroll
     for (int k = 0; k < G::PX; ++k)
-      if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * 512 + wv * 64);
+      if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * NT + wv * 64);
   };
 
   const int NH = npl * ah.Cbp;
@@ -1047,12 +1050,19 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
   do {                                                                                          \
-    using G = HGeo<TN_, TW_>;                                                                   \
+    using G8 = HGeo<TN_, TW_, 8>;                                                               \
+    const long tiles8 = (long)(S / TW_) * (S / G8::TR);                                         \
+    const long grid8 = ((a.N + G8::NPB - 1) / G8::NPB) * a.Z * tiles8 * a.ntile;                \
+    if (grid8 >= 256) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4);                  \
+  } while (0)
+#define TM_LAUNCHHW(TN_, TW_, NWV_)                                                              \
+  do {                                                                                          \
+    using G = HGeo<TN_, TW_, NWV_>;                                                             \
     static bool attr_done = false;                                                              \
     if (!attr_done) {                                                                           \
-      hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, false>,             \
+      hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, false, NWV_>,       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, true>,    \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, true, NWV_>, \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
       attr_done = true;                                                                         \
@@ -1060,14 +1070,15 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
     const long grid = pgs * a.Z * tiles * a.ntile;                                              \
-    if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<TN_, TW_, true>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
-    else hipLaunchKernelGGL((conv27_bf16<TN_, TW_, false>), dim3((unsigned)grid), dim3(512), G::LDS_BYTES, s, ah); \
+    if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<TN_, TW_, true, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+    else hipLaunchKernelGGL((conv27_bf16<TN_, TW_, false, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
   } while (0)
   if (TN == 64) {
     if (S >= 32) TM_LAUNCHH(64, 32); else if (S == 16) TM_LAUNCHH(64, 16); else TM_LAUNCHH(64, 8);
   } else {
     if (S >= 32) TM_LAUNCHH(128, 32); else if (S == 16) TM_LAUNCHH(128, 16); else TM_LAUNCHH(128, 8);
   }
+#undef TM_LAUNCHHW
 #undef TM_LAUNCHH
   return hipGetLastError();
 }
