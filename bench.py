@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark of the denoising hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (starts its own N worker processes when N > 1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one denoising step of the hot path over one batch of synthetic input:
-pad+patchify -> UNet (tm_unet_forward) -> DDPM update (tm_sampler_step) for b=32 images of one
-64x64 interior patch each (BASELINE configs[1]: batch_size=32, patch_size=64, rna_slc=4, T=50
-DDPM, fp32; mode A, P=1 => 128 padded encoder patches, 32 collage decoder patches per step).
-All inputs are resident in HBM before the timed region.  The unit is the interior patch-step
-(SURVEY.md section 8d).  With N > 1 every rank runs its own batch of 32 patches (the path
-shards by independent patches: weak scaling, no data-path collective); the only collectives
-are the one-off RCCL broadcast of rank 0's packed weight arena and the timing barrier.
+Default workload (the headline `value`): a "step" is one denoising step of the hot path over one batch of synthetic
+input: pad+patchify -> UNet (tm_unet_forward) -> DDPM update (tm_sampler_step) for b=32 images of one 64x64 interior
+patch each (BASELINE configs[1]: batch_size=32, patch_size=64, rna_slc=4, T=50 DDPM, fp32; mode A, P=1 => 128 padded
+encoder patches, 32 collage decoder patches per step).  All inputs are resident in HBM before the timed region.  The
+unit is the interior patch-step.  With N > 1 every rank runs its own batch of 32 patches (the
+path shards by independent patches: weak scaling, no data-path collective).
 
-Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, the 3x3x3 implicit-GEMM conv: nominal dense-conv
-FLOPs per launch / average launch duration from hipEvents recorded on the launch stream during
-the timed region, against the fp32 MFMA peak) and `cpu_baseline` (oracle/teramind_cpu.py on the
-host cores, bounded sample).
+Row-sharded tile sweep (`--sweep`, and a short one appended to every default run as the `sweep` object): a fixed ROI of
+`--sweep-hnm x --sweep-wnm` test_brn tiles (256x256 px x 100 channels, 25 z-chunks x 16 interior patches each) in the
+whole-brain configuration (16-bit UNet arithmetic, one float16 state canvas per rank), row-sharded over the N ranks by
+teramind_amd.launch.run_sweep / brain.TileSweep: rank 0's packed weight arena is broadcast once over RCCL and every
+diffusion step ends with the 32-px halo-strip exchange with the neighbouring ranks (send / recv over xGMI).  Strong
+scaling: the ROI is the same for every N.  Reported: interior patch-steps/s of the whole job, per-step exchange time
+and bytes, and the world size as RCCL sees it.
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, the 3x3x3 implicit-GEMM conv: MFMA FLOPs actually
+issued per launch / average launch duration from hipEvents recorded on the launch stream during the timed region,
+against the dense MFMA peak of the dtype) and `cpu_baseline` (oracle/teramind_cpu.py on the host cores, bounded sample).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,8 +37,9 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
-B_IMAGES, P, T_STEPS = 32, 1, 50
-NEEDED_GFLOP_PER_PATCH_STEP = 320.1   # SURVEY.md section 8(d), P=1 (whole path, 2*MAC)
+T_STEPS = 50
+NEEDED_GFLOP = {1: 320.1, 4: 202.6}   # needed FLOPs per interior patch-step (whole path, 2*MAC)
+Z_AWARE = 0.684                       # share of those FLOPs left when the always-zero z tap is not issued
 
 
 _T0 = time.perf_counter()
@@ -42,7 +49,19 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cfg, sd, budget_steps=6, b=8):
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources: `roofline.traffic` (PMC counters, collected in separate rocprofv3 passes and kept
+    under profiles/) is only reported when it was measured on exactly these sources."""
+    d = os.path.join(ROOT, "tera-mind_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(cfg, sd, budget_steps=6, b=8, P=1):
     """Oracle (CPU restatement) timed on this host: `budget_steps` full steps (UNet + DDPM update)
     of b images x 1 interior patch after one warm-up forward."""
     import torch
@@ -80,6 +99,201 @@ def cpu_baseline(cfg, sd, budget_steps=6, b=8):
                       f"fp32 torch CPU oracle, {dt:.1f} s"}
 
 
+def roofline_block(prof, dtype, dt_total, value_per_gpu, P, tile, sweep=False):
+    """`roofline` of the dominant kernel from the hipEvent brackets of the timed region (tm_profile_collect)."""
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    ms = prof["total_ms"]
+    n = max(1, prof["launches"])
+    tfl = lambda fl: fl / (ms * 1e-3) / 1e12 if ms else 0.0
+    executed, nominal = tfl(prof["executed_flops"]), tfl(prof["nominal_flops"])
+    traffic, traffic_src = None, None
+    pmc_json = os.path.join(ROOT, "profiles", "conv27_traffic" + ("_bf16" if dtype != "f32" else "") +
+                            ("_tile" if (tile or sweep) else "") + ".json")
+    if os.path.exists(pmc_json):
+        try:
+            rec = json.load(open(pmc_json))
+            if rec.get("src_sha") == kernel_source_sha():
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = f"{os.path.relpath(pmc_json, ROOT)} @ {rec.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
+            else:
+                traffic_src = f"{os.path.relpath(pmc_json, ROOT)} is stale (kernel sources changed since it was measured): not reported"
+        except Exception:
+            pass
+    whole = NEEDED_GFLOP[P] * Z_AWARE * value_per_gpu / 1e3          # z-aware needed TFLOP/s of the whole step, per GPU
+    return {"bound": "mfma",
+            "kernel": ("conv3d_mfma<2,*,*> (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x2_f32)" if dtype == "f32"
+                       else f"conv27_{dtype} (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x16_{dtype})"),
+            # MFMA FLOPs actually issued (the structurally-zero z tap of the Z = 2 model is never staged nor multiplied:
+            # 2/3 of the dense-conv count) / launch duration, against the dense peak: <= 1 by construction
+            "achieved": round(executed, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "launches_timed": prof["launches"], "avg_launch_ms": round(ms / n, 4),
+            "executed_gflop_per_launch": round(prof["executed_flops"] / n / 1e9, 3),
+            # the reference's own count for the same launches (torch.utils.flop_counter: dense Conv3d incl. the zero tap)
+            "achieved_nominal": round(nominal, 3), "nominal_gflop_per_launch": round(prof["nominal_flops"] / n / 1e9, 3),
+            "alg_gbytes_per_s": round(prof["alg_bytes"] / (ms * 1e-3) / 1e9, 1) if ms else 0.0,
+            "kernel_share_of_step_time": round(ms / (1e3 * dt_total), 4),
+            # every kernel of the step: needed FLOPs per interior patch-step (SURVEY 8d) x 0.684 (z-aware) x patch-steps/s
+            "whole_step_tflops": round(whole, 3), "whole_step_frac": round(whole / peak, 4)}
+
+
+def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
+    """The row-sharded ROI sweep (strong scaling).  Returns the `sweep` result dict (rank 0 fills the JSON from it)."""
+    import torch
+    from teramind_amd import launch
+    from teramind_amd.brain import device_gene_provider
+    from teramind_amd.config import PathConfig
+    from teramind_amd.diffusion import SpacedDiffusionBeatGans
+    from teramind_amd.unet import BeatGANsUNetModel
+    cfg = PathConfig(gen_type="ddim", compute_dtype=args.sweep_dtype)
+    log(f"sweep: packing {args.sweep_dtype} weights")
+    model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
+    T = 15                                                    # test_brn default: 15-step DDIM (test_brn.py:329-330)
+    smp = SpacedDiffusionBeatGans(T, "ddim")
+    genes = device_gene_provider(cfg, dev)
+
+    def on_step(sw, s):
+        if rank == 0:
+            log(f"sweep: step {sw.epoch} done in {s:.2f} s")
+
+    # warm-up steps run unprofiled; the hipEvent brackets cover exactly the timed steps
+    res = launch.run_sweep(cfg, smp, model, genes, hnm=args.sweep_hnm, wnm=args.sweep_wnm, total_epochs=T, steps=steps,
+                           warmup=warmup, device=dev, batch_tiles=args.sweep_batch_tiles, init="device", state="fp16",
+                           on_step=on_step, after_warmup=lambda: model.profile(True))
+    prof = model.profile_collect()
+    model.profile(False)
+    st = res["sweep"].local_state()
+    assert torch.isfinite(st.float()).all(), "non-finite sweep state"
+    tiles = args.sweep_hnm * args.sweep_wnm
+    value = 400.0 * tiles * steps / res["dt"]
+    out = {"value": round(value, 3), "unit": "interior patch-steps/s", "scaling": "strong", "dtype": args.sweep_dtype,
+           "workload": (f"fixed ROI of {args.sweep_hnm} x {args.sweep_wnm} test_brn tiles (256x256 px x 100 channels = 25 z-chunks x "
+                        f"16 interior patches, P=4) per diffusion step, DDIM-15 schedule, {args.sweep_dtype} UNet arithmetic, one "
+                        f"float16 state canvas per rank, tile rows split over {world} rank(s)"),
+           "tiles": tiles, "steps": steps, "warmup": warmup, "s_per_step": round(res["dt"] / steps, 4),
+           "s_per_tile_step_per_gpu": round(res["dt"] / steps / max(1, -(-args.sweep_hnm // world) * args.sweep_wnm), 5),
+           "world_size_rccl": res["world"], "backend": res["backend"],
+           "exchange_ms_per_step": round(res["exchange_ms_per_step"], 3),
+           "exchange_bytes_per_step_per_rank": res["exchange_bytes_per_step"],
+           "weights_broadcast_bytes": int(model.arena().numel()) if world > 1 else 0,
+           "rows_rank0": list(res["rows"])}
+    return out, prof, res["dt"], value
+
+
+def worker(args):
+    import torch
+    import torch.distributed as dist
+    import teramind_amd  # noqa: F401
+    from teramind_amd import launch, synth
+    from teramind_amd.config import PathConfig
+    from teramind_amd.diffusion import SpacedDiffusionBeatGans, pad_patchify, sampler_step
+    from teramind_amd.unet import BeatGANsUNetModel
+    from teramind_amd.weights import hashed_state_dict
+
+    rank, local_rank, world = launch.dist_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    launch.init_distributed("nccl", dev)
+
+    B_IMAGES, P, gen = (25, 4, "ddim") if args.tile else (32, 1, "ddpm")
+    cfg = PathConfig(gen_type=gen, batch_size=B_IMAGES, compute_dtype=args.dtype)
+    log("generating hashed weights")
+    sd = hashed_state_dict(cfg, 0)
+    out = None
+    if not args.sweep:
+        log("packing + uploading weights")
+        model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
+        log("model ready")
+        if world > 1:      # replaces DDP's construction-time parameter broadcast (test_brn.py:149)
+            dist.broadcast(model.arena(), src=0)
+        smp = SpacedDiffusionBeatGans(T_STEPS, gen)
+
+        b, C, ps = B_IMAGES, cfg.in_channels, cfg.patch_size
+        ne = b * (P + 1) ** 2
+        seed = 100 + rank
+        img = synth.normal("bench/xT", (b, C, ps * P, ps * P), seed).to(dev)
+        rna = synth.gene_counts("bench/rna", (ne, cfg.gn_sz, cfg.gn_sz, cfg.rna_slc * 500), seed).to(dev)
+        noise = [synth.normal(f"bench/nz{k}", (ne, C, ps, ps), seed).to(dev) for k in range(4)] if gen == "ddpm" else None
+        shape_only = torch.empty((b, C, ps * P, ps * P), device="meta")
+        tmap = torch.tensor(smp.timestep_map, dtype=torch.int64, device=dev)
+
+        def one_step(k, state):
+            i = T_STEPS - 1 - (k % T_STEPS)
+            xp = pad_patchify(state, ps)
+            t = tmap[i].expand(b).contiguous()
+            eps = model(x=xp, t=t, rna=rna, imgs=shape_only, patch_size=ps).pred
+            return sampler_step(smp, i, xp, eps, noise[k % 4] if gen == "ddpm" else None, b, P, P)
+
+        state = img
+        log("inputs resident; warm-up")
+        for k in range(args.warmup):
+            state = one_step(k, state)
+            torch.cuda.synchronize()
+            log(f"warm-up step {k} done")
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        model.profile(True)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            state = one_step(args.warmup + k, state)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = model.profile_collect()
+        model.profile(False)
+        log(f"timed region done: {dt:.3f} s for {args.steps} steps")
+        if world > 1:
+            dist.barrier()
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert torch.isfinite(state).all(), "non-finite state"
+        del model
+        if rank == 0:
+            units = b * P * P * args.steps * world
+            value = units / dt
+            out = {
+                "metric": "denoising steps/sec on 64x64x(2 stains x 2 z) patches (interior patch-steps/s)",
+                "value": round(value, 3), "unit": "interior patch-steps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                "data": "synthetic (hashed weights seed 0, N(0,1) state/noise, sparse integer gene counts)",
+                "config": {"workload": ("configs[1]: b=32 images x 1 interior 64x64 patch (P=1, 128 padded + 32 collage "
+                                        "patches/step), rna_slc=4, rna_num=229, stain=all, DDPM T=50 schedule, " + args.dtype + ", "
+                                        "mode A (pad+patchify -> UNet -> DDPM update)") if not args.tile else
+                                       ("one test_brn tile per step: 25 z-chunks x (5x5 padded -> 4x4 interior) patches "
+                                        "(P=4, 625 padded + 400 collage patches), DDIM T=50 schedule, mode B arithmetic, " + args.dtype),
+                           "per_gpu_patches_per_step": b * P * P, "parallelism": f"dp{world} (independent patch batches)"},
+                "full_50_step_patches_per_s": round(value / T_STEPS, 4),
+                "roofline": roofline_block(prof, args.dtype, dt, value / world, P, args.tile),
+            }
+    sweep_steps, sweep_warm = (args.steps, args.warmup) if args.sweep else (args.sweep_steps, 1)
+    if args.sweep or not args.no_sweep:
+        torch.cuda.empty_cache()
+        sw_out, sw_prof, sw_dt, sw_value = run_sweep_bench(args, dev, sd, world, rank, sweep_steps, sweep_warm)
+        if rank == 0 and args.sweep:
+            out = {"metric": "denoising steps/sec on 64x64x(2 stains x 2 z) patches (interior patch-steps/s)",
+                   "value": sw_out["value"], "unit": "interior patch-steps/s", "n_gpus": world, "steps": sweep_steps,
+                   "warmup": sweep_warm, "ms_per_step": round(1e3 * sw_dt / sweep_steps, 3), "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": args.sweep_dtype,
+                   "data": "synthetic (hashed weights seed 0, per-tile seeded N(0,1) initial state, sparse integer gene tiles)",
+                   "config": {"workload": sw_out["workload"], "parallelism": f"row-sharded tile grid over {world} rank(s), "
+                              "32-px halo-strip exchange per step (RCCL send/recv), weight arena broadcast once"},
+                   "roofline": roofline_block(sw_prof, args.sweep_dtype, sw_dt, sw_value / world, 4, True, sweep=True),
+                   "sweep": sw_out}
+        elif rank == 0:
+            out["sweep"] = sw_out
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the host cores are shared at N>1)
+            out["cpu_baseline"] = cpu_baseline(PathConfig(), sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,135 +304,20 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline); bf16 = config-4 arithmetic (bf16 3x3x3 convs)")
     ap.add_argument("--tile", action="store_true",
                     help="mode-B workload instead: one test_brn tile (25 z-chunks x 5x5 patches, P=4, DDIM) per step")
-    ap.add_argument("--pmc-json", default=None,
-                    help="rocprofv3 --pmc derived HBM bytes per launch of the dominant conv kernel (default: "
-                         "profiles/conv27_traffic[_bf16][_tile].json for the selected workload)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="measure ONLY the row-sharded tile sweep (strong scaling; --steps / --warmup are diffusion steps of the ROI)")
+    ap.add_argument("--no-sweep", action="store_true", help="default mode: skip the short sweep appended as the `sweep` object")
+    ap.add_argument("--sweep-hnm", type=int, default=8)
+    ap.add_argument("--sweep-wnm", type=int, default=8)
+    ap.add_argument("--sweep-steps", type=int, default=2, help="timed diffusion steps of the appended sweep (1 warm-up step)")
+    ap.add_argument("--sweep-dtype", choices=["bf16", "f16", "f32"], default="bf16")
+    ap.add_argument("--sweep-batch-tiles", type=int, default=1)
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import teramind_amd  # noqa: F401
-    from teramind_amd import synth
-    from teramind_amd.config import PathConfig
-    from teramind_amd.diffusion import SpacedDiffusionBeatGans, pad_patchify, sampler_step
-    from teramind_amd.unet import BeatGANsUNetModel
-    from teramind_amd.weights import hashed_state_dict
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    global B_IMAGES, P
-    gen = "ddpm"
-    if args.tile:
-        B_IMAGES, P, gen = 25, 4, "ddim"
-    cfg = PathConfig(gen_type=gen, batch_size=B_IMAGES, compute_dtype=args.dtype)
-    log("generating hashed weights")
-    sd = hashed_state_dict(cfg, 0)
-    log("packing + uploading weights")
-    model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
-    log("model ready")
-    if world > 1:      # replaces DDP's construction-time parameter broadcast (test_brn.py:149)
-        dist.broadcast(model.arena(), src=0)
-    smp = SpacedDiffusionBeatGans(T_STEPS, gen)
-
-    b, C, ps = B_IMAGES, cfg.in_channels, cfg.patch_size
-    ne = b * (P + 1) ** 2
-    seed = 100 + rank
-    img = synth.normal("bench/xT", (b, C, ps * P, ps * P), seed).to(dev)
-    rna = synth.gene_counts("bench/rna", (ne, cfg.gn_sz, cfg.gn_sz, cfg.rna_slc * 500), seed).to(dev)
-    noise = [synth.normal(f"bench/nz{k}", (ne, C, ps, ps), seed).to(dev) for k in range(4)] if gen == "ddpm" else None
-    shape_only = torch.empty((b, C, ps * P, ps * P), device="meta")
-    tmap = torch.tensor(smp.timestep_map, dtype=torch.int64, device=dev)
-
-    def one_step(k, state):
-        i = T_STEPS - 1 - (k % T_STEPS)
-        xp = pad_patchify(state, ps)
-        t = tmap[i].expand(b).contiguous()
-        eps = model(x=xp, t=t, rna=rna, imgs=shape_only, patch_size=ps).pred
-        return sampler_step(smp, i, xp, eps, noise[k % 4] if gen == "ddpm" else None, b, P, P)
-
-    state = img
-    log("inputs resident; warm-up")
-    for k in range(args.warmup):
-        state = one_step(k, state)
-        torch.cuda.synchronize()
-        log(f"warm-up step {k} done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    model.profile(True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        state = one_step(args.warmup + k, state)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = model.profile_collect()
-    model.profile(False)
-    log(f"timed region done: {dt:.3f} s for {args.steps} steps")
-    if world > 1:
-        dist.barrier()
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(state).all(), "non-finite state"
-
-    if rank == 0:
-        units = b * P * P * args.steps * world
-        value = units / dt
-        avg_ms = prof["total_ms"] / max(1, prof["launches"])
-        achieved = prof["nominal_flops"] / (prof["total_ms"] * 1e-3) / 1e12 if prof["total_ms"] else 0.0
-        traffic = None
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        pmc_json = args.pmc_json or os.path.join(ROOT, "profiles", "conv27_traffic" + ("_bf16" if args.dtype != "f32" else "") +
-                                                 ("_tile" if args.tile else "") + ".json")
-        if os.path.exists(pmc_json):
-            try:
-                traffic = json.load(open(pmc_json)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "denoising steps/sec on 64x64x(2 stains x 2 z) patches (interior patch-steps/s)",
-            "value": round(value, 3), "unit": "interior patch-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic (hashed weights seed 0, N(0,1) state/noise, sparse integer gene counts)",
-            "config": {"workload": ("configs[1]: b=32 images x 1 interior 64x64 patch (P=1, 128 padded + 32 collage "
-                                    "patches/step), rna_slc=4, rna_num=229, stain=all, DDPM T=50 schedule, " + args.dtype + ", "
-                                    "mode A (pad+patchify -> UNet -> DDPM update)") if not args.tile else
-                                   ("one test_brn tile per step: 25 z-chunks x (5x5 padded -> 4x4 interior) patches "
-                                    "(P=4, 625 padded + 400 collage patches), DDIM T=50 schedule, mode B arithmetic"),
-                       "per_gpu_patches_per_step": b * P * P, "parallelism": f"dp{world} (independent patch batches)"},
-            "full_50_step_patches_per_s": round(value / T_STEPS, 4),
-            "roofline": {"bound": "mfma", "kernel": ("conv3d_mfma<2,*,*> (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
-                                                      else f"conv27_{args.dtype} (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x16_{args.dtype})"),
-                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "launches_timed": prof["launches"], "launches_per_step": prof["launches"] // max(1, args.steps),
-                         "avg_launch_ms": round(avg_ms, 4),
-                         "nominal_gflop_per_launch": round(prof["nominal_flops"] / max(1, prof["launches"]) / 1e9, 3),
-                         "executed_mfma_tflops": round(prof["executed_flops"] / (prof["total_ms"] * 1e-3) / 1e12, 3) if prof["total_ms"] else 0.0,
-                         # MFMA instructions actually issued (structurally-zero z taps skipped) over the dense peak: the
-                         # pipe-utilisation figure; `frac` prices the reference's nominal FLOPs and can exceed 1
-                         "frac_executed": round(prof["executed_flops"] / (prof["total_ms"] * 1e-3) / 1e12 / peak, 4) if prof["total_ms"] else 0.0,
-                         "alg_gbytes_per_s": round(prof["alg_bytes"] / (prof["total_ms"] * 1e-3) / 1e9, 1) if prof["total_ms"] else 0.0,
-                         "conv27_share_of_step_time": round(prof["total_ms"] / (1e3 * dt), 4),
-                         "whole_step_needed_tflops": round((NEEDED_GFLOP_PER_PATCH_STEP if P == 1 else 202.6) * value / world / 1e3, 3)},
-        }
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the host cores are shared at N>1)
-            out["cpu_baseline"] = cpu_baseline(cfg, sd)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    from teramind_amd import launch          # imports neither torch nor the HIP library
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # one fresh process per GPU, started before anything in this process touches a GPU (test_brn.py:349-351 mp.spawn)
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    worker(args)
 
 
 if __name__ == "__main__":

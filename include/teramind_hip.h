@@ -197,14 +197,24 @@ int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host
                     int N, int Cin, int Cout, int Z, int S, int ksize, int zmode, int up2,
                     int tile_variant, void* stream);
 
-/* bf16 variant of the 3x3x3 pad-1 conv (Z == 2): x fp32 CB8 is rounded to bf16 (RNE) on the device,
- * w rounded on the host; fp32 accumulate, fp32 CB8 output. */
+/* 16-bit variant of the 3x3x3 pad-1 conv (Z == 2): x fp32 CB8 is rounded to `dtype` (TM_DTYPE_BF16 | TM_DTYPE_F16, RNE) on
+ * the device, w rounded on the host; fp32 accumulate, fp32 CB8 output.  waves: 0 = the launcher's choice, 4 | 8 = force
+ * the 4-wave (128 x 256 / 64 x 512 tile) or 8-wave (128 x 512 / 64 x 1024) workgroup form. */
 int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
-                      int N, int Cin, int Cout, int S, void* stream);
+                      int N, int Cin, int Cout, int S, int dtype, int waves, void* stream);
 
-/* bf16 1x1x1 conv / Linear over '(z h w) c' tokens (x and w rounded to bf16, fp32 accumulate). */
+/* The same conv with the ResBlock mid-section fused into its epilogue (Cout in {64, 128}): out_layers[0]
+ * RMSNorm(C) * norm_w -> x * (1 + scale) + shift -> SiLU (model/MBAblocks.py:196-203,356-367), written as the 16-bit CB8
+ * tensor a2_out [N][Cout/8][2][S][S][8] (the second conv's input).  norm_w [Cout], scale / shift [ceil(N/per_image)][Cout]
+ * HOST fp32; patch n uses row n / per_image. */
+int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const void* bias_host, const void* norm_w_host,
+                       const void* scale_host, const void* shift_host, void* a2_out, int N, int Cin, int Cout,
+                       int S, int per_image, int dtype, int waves, void* stream);
+
+/* 16-bit 1x1x1 conv / Linear over '(z h w) c' tokens (x and w rounded to `dtype`, fp32 accumulate).  waves: 0 | 4 | 8
+ * as above (two co-resident 4-wave workgroups per CU, or one 8-wave workgroup). */
 int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
-                     int N, int Cin, int Cout, int Z, int S, int gelu, void* stream);
+                     int N, int Cin, int Cout, int Z, int S, int gelu, int dtype, int waves, void* stream);
 
 /* Windowed gene-patch cross attention core (model/MBAblocks.py:551-601 between the q/k/v Linears and proj):
  * q, k, v fp32 CB8 [N, C, Z, S, S]; qw, kw: device fp32 [C] (q_norm / k_norm weights).

@@ -6,8 +6,9 @@ bench.py's `cpu_baseline` leg may import it, and only as the checker / the timed
 baseline -- never as a product code path.
 
 Pinning: validated in the build container against the real reference imported on CPU
-(tests/test_oracle_vs_reference.py, skipped when /root/reference is absent) and against the
-golden vectors under tests/golden/ that oracle/make_golden.py minted from the reference.
+(oracle/ref_harness.py + oracle/make_golden.py, which import /root/reference and cannot run on the GPU box) and,
+everywhere, against the golden vectors under tests/golden/ that those scripts minted from the reference
+(tests/test_oracle_golden.py).
 One boundary is "parity unpinned": timm's `Mlp` (third-party, timm==1.0.14, absent here);
 it is restated as fc1 -> GELU(tanh) -> fc2 per the reference call site model/MBAblocks.py:461.
 

@@ -71,6 +71,9 @@ class TileSweep:
         W = wnm * tiles.TILE + 2 * PAD
         self.epoch = 0
         self._pending, self._noise_rows, self._strips = {}, {}, {}
+        # halo-exchange accounting (bench.py --sweep): seconds (device-synchronised when time_exchange is set), bytes
+        # sent + received by this rank, number of exchanges
+        self.time_exchange, self.exchange_s, self.exchange_bytes, self.exchanges = False, 0.0, 0, 0
         if state == "fp16":
             self.cur = torch.full((self.chn, H, W), -1.0, dtype=torch.float16, device=self.dev)
             self.nxt = None
@@ -137,28 +140,52 @@ class TileSweep:
         for lr in sorted(k for k in self._pending if k <= upto):
             self.cur[:, PAD + lr * tiles.TILE:PAD + (lr + 1) * tiles.TILE, PAD:-PAD].copy_(self._pending.pop(lr))
 
+    def _neighbours(self):
+        """(up, down): the nearest ranks above / below that own tile rows, or None.  With more ranks than tile rows
+        (world > hnm: the trailing ranks of tiles.row_block_partition own nothing) the empty ranks take no part in the
+        exchange, and the last rank with rows has no partner below it."""
+        part = tiles.row_block_partition(self.hnm, self.world)
+        has = [r1 > r0 for r0, r1 in part]
+        up = next((r for r in range(self.rank - 1, -1, -1) if has[r]), None)
+        down = next((r for r in range(self.rank + 1, self.world) if has[r]), None)
+        return up, down
+
     def _exchange(self, canvas):
-        """32-px strips to / from the neighbouring ranks (full canvas width: corners included)."""
+        """32-px strips to / from the neighbouring ranks (full canvas width: corners included).  RCCL send / recv over
+        xGMI when the group's backend is nccl; with gloo the strips are staged through host memory (CPU tests, and
+        multi-process runs that share one GPU)."""
         if self.world == 1 or self.nrows == 0:
             return
+        import time
         import torch.distributed as dist
+        up, down = self._neighbours()
+        if up is None and down is None:
+            return
+        timed = self.time_exchange and canvas.is_cuda
+        if timed:
+            torch.cuda.synchronize(canvas.device)
+        t0 = time.perf_counter()
+        via_host = canvas.is_cuda and dist.get_backend(self.group) == "gloo"
         ops, bufs = [], []
         H = canvas.shape[1]
-        up, down = self.rank - 1, self.rank + 1
-        if up >= 0:
-            send = canvas[:, PAD:2 * PAD, :].contiguous()
+        for peer, src, dst in ((up, slice(PAD, 2 * PAD), slice(0, PAD)), (down, slice(H - 2 * PAD, H - PAD), slice(H - PAD, H))):
+            if peer is None:
+                continue
+            send = canvas[:, src, :].contiguous()
+            if via_host:
+                send = send.cpu()
             recv = torch.empty_like(send)
-            ops += [dist.P2POp(dist.isend, send, up, self.group), dist.P2POp(dist.irecv, recv, up, self.group)]
-            bufs.append((recv, slice(0, PAD)))
-        if down < self.world:
-            send = canvas[:, H - 2 * PAD:H - PAD, :].contiguous()
-            recv = torch.empty_like(send)
-            ops += [dist.P2POp(dist.isend, send, down, self.group), dist.P2POp(dist.irecv, recv, down, self.group)]
-            bufs.append((recv, slice(H - PAD, H)))
+            ops += [dist.P2POp(dist.isend, send, peer, self.group), dist.P2POp(dist.irecv, recv, peer, self.group)]
+            bufs.append((recv, dst))
+            self.exchange_bytes += 2 * send.numel() * send.element_size()
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for recv, sl in bufs:
             canvas[:, sl, :].copy_(recv)
+        if timed:
+            torch.cuda.synchronize(canvas.device)
+        self.exchange_s += time.perf_counter() - t0
+        self.exchanges += 1
 
     # ---- one diffusion step over the rank's tiles ----------------------------------------------
     def _window(self, lr: int, c: int) -> torch.Tensor:
@@ -281,6 +308,27 @@ def synthetic_gene_provider(conf: PathConfig, total_slc: int = 50, density: floa
             z = torch.zeros((cells, cells, zpad * tiles.GENES))
             core = torch.cat((z, core, z), dim=-1)
         return core.to(device)
+    return provider
+
+
+def device_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density: float = 0.02):
+    """Synthetic gene tiles generated and kept on the device: [20, 20, (total_slc + 2 zpad) * 500] sparse non-negative
+    integer counts, a pure function of the absolute tile position (so every rank sees the same tile for (row, col))."""
+    cache = {}
+    zpad = Z_PAD[cfg.rna_slc] * tiles.GENES
+    cells = (tiles.TILE + 2 * PAD) // (cfg.patch_size // cfg.gn_sz)
+
+    def provider(row, col):
+        if (row, col) not in cache:
+            g = torch.Generator(device=dev)
+            g.manual_seed(1_000_003 * row + col)
+            u = torch.rand((cells, cells, total_slc * tiles.GENES), generator=g, device=dev)
+            core = torch.where(u < density, torch.floor(u * (3.0 / density)) + 1.0, torch.zeros_like(u))
+            if zpad:
+                z = torch.zeros((cells, cells, zpad), device=dev)
+                core = torch.cat((z, core, z), dim=-1)
+            cache[(row, col)] = core
+        return cache[(row, col)]
     return provider
 
 

@@ -279,11 +279,11 @@ hipError_t launch_gene_attn(const float* rna, int B, int gn, int zs, int G, cons
   a.out_tok = out_tok; a.attn_map = attn_map; a.scratch = out_tok;   // norm2 output staged in-place
   a.zlo = zlo; a.zhi = zhi;
   const size_t lds2 = ((size_t)2 * GROWS * GTP + 640) * sizeof(float);
-  static bool attr2 = false;
-  if (!attr2) {
+  static DevOnce attr2;
+  if (attr2.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gene_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr2 = true;
+    attr2.mark();
   }
   hipLaunchKernelGGL(gene_attn_mfma_kernel, dim3(B, B >= 256 ? 1 : 2), dim3(256), lds2, s, a);
   return hipGetLastError();
@@ -516,11 +516,11 @@ hipError_t launch_gene_attn_generic(const float* rna, int B, int gn, int zs, int
   ga.D = D; ga.gidx = gidx; ga.ws = ws; ga.ws_stride = (long)gene_generic_ws_floats(G, D);
   const int Gp = (G + 63) / 64 * 64;
   const size_t lds = (size_t)4 * GG_RB * (4 * D + Gp) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gene_attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.mark();
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gene_attn_generic_kernel, dim3(B, gene_generic_split(B)), dim3(256), lds, s, ga);
@@ -1156,11 +1156,11 @@ __global__ __launch_bounds__(256) void window_attn_generic_kernel(WinArgs a, int
 template <int T>
 static hipError_t launch_win(const WinArgs& a, int N, hipStream_t s) {
   const size_t lds = ((size_t)3 * T + 2 * 16 * T + (size_t)T * (T + 4) + 16 * 128) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)window_attn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(window_attn_kernel<T>, dim3(N * 4), dim3(256), lds, s, a);
   return hipGetLastError();
@@ -1179,12 +1179,12 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
     const size_t lds = ((size_t)(128 + 32) * WinLongLds::PS + 128 + 2 * T + a.C) * sizeof(float);
 #define TM_LAUNCHWL(T_)                                                                                              \
   do {                                                                                                               \
-    static bool lattr = false;                                                                                       \
-    if (!lattr) {                                                                                                    \
+    static DevOnce lattr;                                                                                       \
+    if (lattr.need()) {                                                                                                    \
       hipError_t e = hipFuncSetAttribute((const void*)window_attn_mfma_long_kernel<T_>,                              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       if (e != hipSuccess) return e;                                                                                 \
-      lattr = true;                                                                                                  \
+      lattr.mark();                                                                                                  \
     }                                                                                                                \
     hipLaunchKernelGGL(window_attn_mfma_long_kernel<T_>, dim3(q.N * 4 * (T_ / 128)), dim3(256), lds, s, a);          \
   } while (0)
@@ -1195,22 +1195,22 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
   if ((T != 128 && T != 32) || a.C % 128) {            // the other configurations: generic kernel (fp32 output only)
     if (T > 512 || a.C > 512 || o_h) return hipErrorInvalidValue;
     const size_t lds = ((size_t)3 * T + a.C + 4 * WQ * (a.C + T)) * sizeof(float);
-    static bool gattr = false;
-    if (!gattr) {
+    static DevOnce gattr;
+    if (gattr.need()) {
       hipError_t e = hipFuncSetAttribute((const void*)window_attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
-      gattr = true;
+      gattr.mark();
     }
     hipLaunchKernelGGL(window_attn_generic_kernel, dim3(q.N * 4), dim3(256), lds, s, a, T);
     return hipGetLastError();
   }
   if (T == 128 && a.C <= 512) {
-    static bool attr_set = false;
+    static DevOnce attr_set;
     const size_t lds = (size_t)WinLds::FLOATS * sizeof(float);
-    if (!attr_set) {
+    if (attr_set.need()) {
       hipError_t e = hipFuncSetAttribute((const void*)window_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      attr_set.mark();
     }
     hipLaunchKernelGGL(window_attn_mfma_kernel, dim3(q.N * 4), dim3(256), lds, s, a);
     return hipGetLastError();

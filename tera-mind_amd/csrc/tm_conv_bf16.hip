@@ -857,12 +857,12 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
     if (a.C > 256) return hipErrorInvalidValue;
 #define TM_LAUNCHWL(T_)                                                                                     \
   do {                                                                                                      \
-    static bool attr_set = false;                                                                           \
-    if (!attr_set) {                                                                                        \
+    static DevOnce attr_set;                                                                           \
+    if (attr_set.need()) {                                                                                        \
       hipError_t e = hipFuncSetAttribute((const void*)window_attn_long<T_>,                                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, WLGeo<T_>::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                                        \
-      attr_set = true;                                                                                      \
+      attr_set.mark();                                                                                      \
     }                                                                                                       \
     hipLaunchKernelGGL(window_attn_long<T_>, dim3((unsigned)(q.N * 4 * WLGeo<T_>::QBN)), dim3(256),         \
                        WLGeo<T_>::LDS_BYTES, s, a);                                                         \
@@ -874,12 +874,12 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
   if (T != 128 && T != 64 && T != 32) return hipErrorInvalidValue;
 #define TM_LAUNCHWA(T_)                                                                                     \
   do {                                                                                                      \
-    static bool attr_set = false;                                                                           \
-    if (!attr_set) {                                                                                        \
+    static DevOnce attr_set;                                                                           \
+    if (attr_set.need()) {                                                                                        \
       hipError_t e = hipFuncSetAttribute((const void*)window_attn_bf16<T_>,                                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, WAGeo<T_>::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                                        \
-      attr_set = true;                                                                                      \
+      attr_set.mark();                                                                                      \
     }                                                                                                       \
     hipLaunchKernelGGL(window_attn_bf16<T_>, dim3((unsigned)(q.N * (4 / WAGeo<T_>::WPW))), dim3(256),       \
                        WAGeo<T_>::LDS_BYTES, s, a);                                                         \
@@ -970,19 +970,34 @@ void conv1_bf16_pack_host(const float* w /*[Cout][Cin]*/, int Cout, const int* s
 }
 
 static const void* zero_page(hipError_t* err) {
-  static void* zp = nullptr;                            // 256 B of zeros, lives for the process
-  if (!zp) {
-    hipError_t e = hipMalloc(&zp, 256);
-    if (e == hipSuccess) e = hipMemset(zp, 0, 256);
-    if (e != hipSuccess) { *err = e; zp = nullptr; }
+  static void* zp[128] = {nullptr};                     // 256 B of zeros per device, lives for the process
+  const int d = DevOnce::dev();
+  if (!zp[d]) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, 256);
+    if (e == hipSuccess) e = hipMemset(p, 0, 256);
+    if (e != hipSuccess) { *err = e; return nullptr; }
+    zp[d] = p;
   }
-  return zp;
+  return zp[d];
+}
+#ifdef TM_H16_F16
+hipError_t init_f16_device() {
+#else
+hipError_t init_bf16_device() {
+#endif
+  // everything a first launch would otherwise set up lazily that is NOT a stream operation (a device allocation and a
+  // synchronous memset): done at tm_model_finalize so that a forward can be captured into a graph from its first call
+  hipError_t e = hipSuccess;
+  return zero_page(&e) ? hipSuccess : e;
 }
 
-static bool tm_conv1_small_wg() {        // TM_CONV1_WAVES=8 selects the single 8-wave workgroup per CU (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TM_CONV1_WAVES"); v = (e && atoi(e) == 8) ? 0 : 1; }
-  return v == 1;
+// A/B switches (environment, read once): TM_CONV1_WAVES / TM_CONV27_WAVES = 4 | 8 force the workgroup form of every
+// launch that does not name one itself (ConvLaunchH::force_waves, the tm_op_* test entry points)
+static int env_waves(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return (v == 4 || v == 8) ? v : 0;
 }
 
 hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
@@ -1010,17 +1025,20 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
 #define TM_LAUNCH1H(TN_, NWV_)                                                                   \
   do {                                                                                          \
     using G = H1Geo<TN_, NWV_>;                                                                 \
-    static bool attr_done = false;                                                              \
-    if (!attr_done) {                                                                           \
+    static DevOnce attr_done;                                                              \
+    if (attr_done.need()) {                                                                           \
       hipError_t e = hipFuncSetAttribute((const void*)conv1_bf16<TN_, NWV_>,                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
-      attr_done = true;                                                                         \
+      attr_done.mark();                                                                         \
     }                                                                                           \
     const long grid = ((vox + G::TM - 1) / G::TM) * a.ntile;                                    \
     hipLaunchKernelGGL((conv1_bf16<TN_, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah, zp); \
   } while (0)
-  const bool small_wg = tm_conv1_small_wg();
+  static const int env1 = env_waves("TM_CONV1_WAVES");
+  const int fw1 = L.force_waves ? L.force_waves : env1;
+  if (fw1 != 0 && fw1 != 4 && fw1 != 8) return hipErrorInvalidValue;
+  const bool small_wg = fw1 != 8;                       // default: two co-resident 4-wave workgroups per CU
   if (TN == 64) { if (small_wg) TM_LAUNCH1H(64, 4); else TM_LAUNCH1H(64, 8); }
   else { if (small_wg) TM_LAUNCH1H(128, 4); else TM_LAUNCH1H(128, 8); }
 #undef TM_LAUNCH1H
@@ -1048,24 +1066,28 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
   if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
+  static const int env27 = env_waves("TM_CONV27_WAVES");
+  const int fw27 = L.force_waves ? L.force_waves : env27;
+  if (fw27 != 0 && fw27 != 4 && fw27 != 8) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
   do {                                                                                          \
     using G8 = HGeo<TN_, TW_, 8>;                                                               \
     const long tiles8 = (long)(S / TW_) * (S / G8::TR);                                         \
     const long grid8 = ((a.N + G8::NPB - 1) / G8::NPB) * a.Z * tiles8 * a.ntile;                \
-    if (grid8 >= 256) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4);                  \
+    const bool w8 = fw27 ? fw27 == 8 : grid8 >= 256;                                            \
+    if (w8) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4);                            \
   } while (0)
 #define TM_LAUNCHHW(TN_, TW_, NWV_)                                                              \
   do {                                                                                          \
     using G = HGeo<TN_, TW_, NWV_>;                                                             \
-    static bool attr_done = false;                                                              \
-    if (!attr_done) {                                                                           \
+    static DevOnce attr_done;                                                              \
+    if (attr_done.need()) {                                                                           \
       hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, false, NWV_>,       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_bf16<TN_, TW_, true, NWV_>, \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
-      attr_done = true;                                                                         \
+      attr_done.mark();                                                                         \
     }                                                                                           \
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \

@@ -9,6 +9,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TM_EPS 1e-6f
+
+// Host-side once-per-DEVICE flag for lazy launch setup (hipFuncSetAttribute applies to the current device's code
+// object, so a per-process `static bool` would leave every device but the first without its LDS limit).
+struct DevOnce {
+  unsigned long long done[2] = {0ull, 0ull};           // devices 0..127
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 127; }
+  bool need() const { const int d = dev(); return !((done[d >> 6] >> (d & 63)) & 1ull); }
+  void mark() { const int d = dev(); done[d >> 6] |= 1ull << (d & 63); }
+};
 #ifndef TM_H16_T
 #define TM_H16_T __bf16          // 16-bit float type of the y_h / gate_h tensors in this translation unit (tm_conv_bf16.hip)
 #endif

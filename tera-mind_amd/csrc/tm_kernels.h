@@ -82,7 +82,10 @@ struct ConvLaunchH {
   long mod_stride = 0;
   int per_image = 1;
   TVH a2;
+  int force_waves = 0;              // 0 = auto, 4 | 8 = workgroup form (tests / A-B; TM_CONV27_WAVES, TM_CONV1_WAVES)
 };
+hipError_t init_bf16_device();      // per-device set-up that must not happen lazily inside a stream capture
+hipError_t init_f16_device();
 int conv_bf16_tn(int Cout);
 size_t conv1_bf16_pack_elems(int Cout, int Cbi);
 void conv1_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);

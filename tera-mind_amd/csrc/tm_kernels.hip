@@ -391,12 +391,12 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
 #define TM_LAUNCH3(NZI, WM, TW)                                                                  \
   do {                                                                                          \
     using G = C3Geo<NZI, WM, TW>;                                                               \
-    static bool attr_done = false;                                                              \
-    if (!attr_done) {                                                                           \
+    static DevOnce attr_once;                                                                   \
+    if (attr_once.need()) {                                                                     \
       hipError_t e = hipFuncSetAttribute((const void*)conv3d_mfma<NZI, WM, TW>,                 \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
-      attr_done = true;                                                                         \
+      attr_once.mark();                                                                         \
     }                                                                                           \
     const long tiles = (long)(S / TW) * (S / G::TR);                                            \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \

@@ -593,6 +593,7 @@ extern "C" int tm_model_finalize(tm_model* m) {
   HIP_TRY(hipMemcpy(m->arena, pk.buf.data(), m->arena_floats * sizeof(float), hipMemcpyHostToDevice));
   for (Fix& f : fx) *f.slot = m->arena + f.off;
   for (FixH& f : fxh) *f.slot = (const uint16_t*)(m->arena + f.off);
+  if (bf16) HIP_TRY(c.dtype == TM_DTYPE_F16 ? init_f16_device() : init_bf16_device());
   m->host.clear();
   m->finalized = true;
   return TM_OK;
@@ -1210,47 +1211,83 @@ extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv_mfma execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
-extern "C" int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
-                                 int Cout, int S, void* stream) {
+// shared body of the 16-bit 3x3x3 conv test entry points: fp32 CB8 input -> 16-bit CB8 (prep kernel), then the conv
+static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin, int Cout,
+                         int S, int dtype, int waves, const void* norm_w_host, const void* scale_host, const void* shift_host,
+                         int per_image, void* a2_out, void* stream) {
+  if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
+  if (waves != 0 && waves != 4 && waves != 8) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4 or 8");
+  const bool f16 = dtype == TM_DTYPE_F16, fused = norm_w_host != nullptr;
+  if (fused && (!scale_host || !shift_host || !a2_out || per_image < 1 || (Cout != 64 && Cout != 128)))
+    return fail(TM_ERR_ARG, "fused epilogue needs Cout in {64, 128}, scale / shift / a2 and per_image >= 1");
   hipStream_t st = (hipStream_t)stream;
   const int Cbi = (Cin + 7) / 8, Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64;
   std::vector<uint16_t> pk(conv_bf16_pack_elems(Cout, Cbi));
-  conv_bf16_pack_host((const float*)w_host, Cout, &Cin, 1, pk.data());
-  std::vector<float> bp((size_t)nt64 * 64, 0.f);
-  memcpy(bp.data(), bias_host, Cout * sizeof(float));
+  (f16 ? conv_f16_pack_host : conv_bf16_pack_host)((const float*)w_host, Cout, &Cin, 1, pk.data());
+  const int nimg = (N + per_image - 1) / per_image;
+  // one device buffer of floats: bias | norm_w | scale [nimg][Cout] | shift [nimg][Cout]
+  std::vector<float> fp((size_t)nt64 * 64 + (fused ? (size_t)Cout * (1 + 2 * nimg) : 0), 0.f);
+  memcpy(fp.data(), bias_host, Cout * sizeof(float));
+  if (fused) {
+    memcpy(fp.data() + nt64 * 64, norm_w_host, Cout * sizeof(float));
+    memcpy(fp.data() + nt64 * 64 + Cout, scale_host, (size_t)nimg * Cout * sizeof(float));
+    memcpy(fp.data() + nt64 * 64 + Cout + (size_t)nimg * Cout, shift_host, (size_t)nimg * Cout * sizeof(float));
+  }
   uint16_t *dw = nullptr, *dx = nullptr;
-  float* db = nullptr;
+  float* df = nullptr;
   const long vox = (long)2 * S * S;
   HIP_TRY(hipMalloc((void**)&dw, pk.size() * sizeof(uint16_t)));
-  HIP_TRY(hipMalloc((void**)&db, bp.size() * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&df, fp.size() * sizeof(float)));
   HIP_TRY(hipMalloc((void**)&dx, (size_t)N * Cbe * vox * 8 * sizeof(uint16_t)));
   HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(df, fp.data(), fp.size() * sizeof(float), hipMemcpyHostToDevice));
   TV x = view_cb8(const_cast<void*>(x_cb8), N, Cin, 2, S, S);
-  PrepLaunch P;                       // fp32 CB8 -> bf16 CB8 (no norm / act), pair padding
+  PrepLaunch P;                       // fp32 CB8 -> 16-bit CB8 (no norm / act), pair padding
   P.nsrc = 1;
   P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
-  P.N = N; P.Z = 2; P.S = S;
+  P.N = N; P.Z = 2; P.S = S; P.h_f16 = f16 ? 1 : 0;
   P.out_h = dx; P.out_h_nstride = (long)Cbe * vox * 8; P.pad_blocks = Cbe - Cbi;
   hipError_t e0 = launch_prep(P, st);
   ConvLaunchH L;
   L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = 2; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
-  L.w = dw; L.bias = db; L.Cout = Cout;
+  L.w = dw; L.bias = df; L.Cout = Cout; L.force_waves = waves;
   L.y = view_cb8(y_cb8, N, Cout, 2, S, S);
-  hipError_t e = launch_conv27_bf16(L, st);
+  if (fused) {
+    L.fuse_norm = 1; L.norm_w = df + nt64 * 64; L.mod_scale = L.norm_w + Cout; L.mod_shift = L.mod_scale + (size_t)nimg * Cout;
+    L.mod_stride = Cout; L.per_image = per_image;
+    L.a2.p = (uint16_t*)a2_out; L.a2.N = N; L.a2.Cb = Cout / 8; L.a2.C = Cout; L.a2.Z = 2; L.a2.H = S; L.a2.W = S;
+    L.a2.nstride = (long)(Cout / 8) * vox * 8;
+  }
+  hipError_t e = (f16 ? launch_conv27_f16 : launch_conv27_bf16)(L, st);
   hipError_t e2 = hipStreamSynchronize(st);
-  (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dx);
+  (void)hipFree(dw); (void)hipFree(df); (void)hipFree(dx);
   if (e0 != hipSuccess) return fail(TM_ERR_HIP, "launch_prep: %s", hipGetErrorString(e0));
-  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv27_bf16: %s", hipGetErrorString(e));
-  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv27_bf16 execution: %s", hipGetErrorString(e2));
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv27 (16-bit): %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv27 (16-bit) execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
+extern "C" int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
+                                 int Cout, int S, int dtype, int waves, void* stream) {
+  if (!x_cb8 || !w_host || !bias_host || !y_cb8) return fail(TM_ERR_ARG, "null argument");
+  return op_conv27_h16(x_cb8, w_host, bias_host, y_cb8, N, Cin, Cout, S, dtype, waves, nullptr, nullptr, nullptr, 1, nullptr, stream);
+}
+extern "C" int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const void* bias_host, const void* norm_w_host,
+                                  const void* scale_host, const void* shift_host, void* a2_out, int N, int Cin, int Cout,
+                                  int S, int per_image, int dtype, int waves, void* stream) {
+  if (!x_cb8 || !w_host || !bias_host || !norm_w_host || !a2_out) return fail(TM_ERR_ARG, "null argument");
+  // the launcher takes the output geometry from `y`; the fused form never writes it
+  return op_conv27_h16(x_cb8, w_host, bias_host, a2_out, N, Cin, Cout, S, dtype, waves, norm_w_host, scale_host, shift_host,
+                       per_image, a2_out, stream);
+}
 extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
-                                int Cout, int Z, int S, int gelu, void* stream) {
+                                int Cout, int Z, int S, int gelu, int dtype, int waves, void* stream) {
+  if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
+  if (waves != 0 && waves != 4 && waves != 8) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4 or 8");
+  const bool f16 = dtype == TM_DTYPE_F16;
   hipStream_t st = (hipStream_t)stream;
   const int Cbi = (Cin + 7) / 8, Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64;
   std::vector<uint16_t> pk(conv1_bf16_pack_elems(Cout, Cbi));
-  conv1_bf16_pack_host((const float*)w_host, Cout, &Cin, 1, pk.data());
+  (f16 ? conv1_f16_pack_host : conv1_bf16_pack_host)((const float*)w_host, Cout, &Cin, 1, pk.data());
   std::vector<float> bp((size_t)nt64 * 64, 0.f);
   memcpy(bp.data(), bias_host, Cout * sizeof(float));
   uint16_t *dw = nullptr, *dx = nullptr;
@@ -1265,19 +1302,19 @@ extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const voi
   PrepLaunch P;
   P.nsrc = 1;
   P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
-  P.N = N; P.Z = Z; P.S = S;
+  P.N = N; P.Z = Z; P.S = S; P.h_f16 = f16 ? 1 : 0;
   P.out_h = dx; P.out_h_nstride = (long)Cbe * vox * 8; P.pad_blocks = Cbe - Cbi;
   hipError_t e0 = launch_prep(P, st);
   ConvLaunchH L;
   L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = Z; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
-  L.w = dw; L.bias = db; L.Cout = Cout; L.flags = gelu ? EPI_GELU : 0;
+  L.w = dw; L.bias = db; L.Cout = Cout; L.flags = gelu ? EPI_GELU : 0; L.force_waves = waves;
   L.y = view_cb8(y_cb8, N, Cout, Z, S, S);
-  hipError_t e = launch_conv1_bf16(L, st);
+  hipError_t e = (f16 ? launch_conv1_f16 : launch_conv1_bf16)(L, st);
   hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dx);
   if (e0 != hipSuccess) return fail(TM_ERR_HIP, "launch_prep: %s", hipGetErrorString(e0));
-  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv1_bf16: %s", hipGetErrorString(e));
-  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1_bf16 execution: %s", hipGetErrorString(e2));
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv1 (16-bit): %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1 (16-bit) execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
 extern "C" int tm_op_window_attn(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_dev,

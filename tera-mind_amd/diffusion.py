@@ -187,7 +187,14 @@ class SpacedDiffusionBeatGans:
                x_T: Optional[torch.Tensor] = None,
                step_noise: Union[None, Sequence[torch.Tensor], Callable[[int], torch.Tensor]] = None):
         """mode A (idx None): full reverse loop from x_T over an image of `shape`;
-        mode B (idx given, `imgs` = padded patch batch): the single step `idx` (test_brn)."""
+        mode B (idx given, `imgs` = padded patch batch): the single step `idx` (test_brn).
+        `clip_denoised` must be True (the value both reference callers use, base.py:305; test_brn.py:209-217 and
+        experiment.py:325-330 never pass it): the x0 clamp of base.py:423-427 is part of the step kernel.
+        `cond` / `x_start` are forwarded to the model by the reference (base.py:311-316) and ignored by the `ours` model;
+        they are accepted and ignored here too."""
+        if not clip_denoised:
+            raise NotImplementedError("clip_denoised=False: tm_sampler_step always clamps the x0 prediction to [-1, 1] "
+                                      "(diffusion/base.py:423-427); the reference never samples without it")
         final = None
         for final in self.sample_progressive(model, shape, noise, r_start, imgs, idx, x_T=x_T, step_noise=step_noise):
             pass

@@ -104,6 +104,36 @@ def test_single_fp16_canvas_state_is_bit_identical(batch_tiles):
     assert not sw._pending and not sw._strips
 
 
+@pytest.mark.parametrize("world,hnm,state", [(2, HNM, "fp32x2"), (2, HNM, "fp16"), (2, 1, "fp32x2"), (3, 2, "fp16")])
+def test_launcher_and_rank_entry_of_the_gpu_sweep(world, hnm, state, tmp_path):
+    """The product launcher (launch.spawn_ranks: what `bench.py --gpus N` starts its ranks with) and the product rank
+    entry (launch.run_sweep: what `bench.py --sweep` / tools/run_roi.py run per GPU), on CPU under gloo: every rank's
+    rows equal the single-rank sweep bit for bit.  world > hnm (more ranks than tile rows: trailing ranks own nothing
+    and must stay out of the strip exchange) used to hang the last rank that has rows."""
+    import numpy as np
+    from teramind_amd import launch
+    torch.set_num_threads(4)
+    ref = TileSweep(PathConfig(), StandInSampler(), None, gene_provider, hst=512, wst=768, hnm=hnm, wnm=WNM, total_epochs=T,
+                    total_slc=SLC, device="cpu").test()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sweep_worker.py")
+    rc = launch.spawn_ranks(world, [worker, str(tmp_path), str(hnm), str(WNM), state], timeout=600)
+    assert rc == 0, f"rank processes failed / timed out (exit code {rc})"
+    rows_seen = 0
+    for r in range(world):
+        r0, r1, w, backend, xbytes, nx = open(tmp_path / f"rank{r}.txt").read().split()
+        r0, r1 = int(r0), int(r1)
+        assert int(w) == world and backend == "gloo"
+        got = torch.from_numpy(np.load(tmp_path / f"rank{r}.npy"))
+        assert got.shape == (SLC * 2, (r1 - r0) * 256, WNM * 256)
+        assert torch.equal(got, ref[:, r0 * 256:r1 * 256, :]), f"rank {r} rows [{r0},{r1}) differ from the single-rank sweep"
+        if r1 > r0 and min(world, hnm) > 1:
+            assert int(nx) > 0 and int(xbytes) > 0                   # it did exchange strips
+        if r1 == r0:
+            assert int(nx) == 0                                      # an empty rank stays out of the exchange
+        rows_seen += r1 - r0
+    assert rows_seen == hnm
+
+
 def test_halo_dependence_is_real():
     """Sanity of the stand-in: without the exchange the two-rank result would differ."""
     sw = make_sweep(0, 1)

@@ -94,14 +94,24 @@ def test_config1_full_50_step_loop_properties():
     assert not torch.equal(a[10], a[11])
 
 
-def test_tile_config_interior_patch_locality():
-    """mode B geometry at full tile size: 25 z-chunks x 5x5 padded patches (625 encoder, 400 decoder patches)."""
-    b, P = 25, 4
+def _tile_inputs(b=25, P=4):
     p = P + 1
     x = synth.normal("tile/x", (b * p * p, 4, 64, 64), 5)
     rna = synth.gene_counts("tile/rna", (b * p * p, 4, 4, 2000), 5)
     t = torch.full((b,), 601, dtype=torch.long)
-    m = model()
+    return x, rna, t
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_tile_config_interior_patch_locality(dtype):
+    """mode B geometry at full tile size: 25 z-chunks x 5x5 padded patches (625 encoder, 400 decoder patches) -- the
+    shape of BASELINE configs[2] / configs[3] (test_brn.py:188-208), in fp32 and in both 16-bit arithmetic types (the
+    whole-brain config runs bf16).  The per-voxel arithmetic does not depend on which other patches share the launch, so
+    an interior patch of the P = 4 call equals the P = 1 call on its own four encoder patches."""
+    b, P = 25, 4
+    p = P + 1
+    x, rna, t = _tile_inputs(b, P)
+    m = model(dtype)
     big = m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.empty((b, 4, 64 * P, 64 * P), device="meta"), patch_size=64).pred
     assert big.shape == (b * P * P, 4, 64, 64) and torch.isfinite(big).all()
     for img, i, j in ((0, 0, 0), (7, 1, 2), (24, 3, 3)):
@@ -110,7 +120,56 @@ def test_tile_config_interior_patch_locality():
                   patch_size=64).pred
         got = big[img * P * P + i * P + j]
         d = (got - small[0]).abs().max().item()
-        assert d <= 1e-5, f"interior patch ({img},{i},{j}): P=4 vs P=1 differ by {d}"
+        assert d <= 1e-5, f"{dtype}: interior patch ({img},{i},{j}): P=4 vs P=1 differ by {d}"
+
+
+# measured on one MI355X (relative L2 vs the fp32 CPU oracle on eps of std ~0.57): bf16 4e-3, f16 5e-4
+TILE_TOL = {"f32": (1e-5, 2e-4), "bf16": (6e-3, 0.04), "f16": (8e-4, 5e-3)}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_tile_config_oracle_on_two_z_chunks(dtype):
+    """The full test_brn tile call (b = 25 z-chunks, P = 4) against the CPU oracle on its first two z-chunks (the oracle
+    needs ~7 s per z-chunk at this shape; z-chunks are independent images of the call)."""
+    b, P, nz = 25, 4, 2
+    p = P + 1
+    x, rna, t = _tile_inputs(b, P)
+    m = model(dtype)
+    big = m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.empty((b, 4, 64 * P, 64 * P), device="meta"), patch_size=64).pred
+    sd, oc = util.state_dict(PathConfig()), tc.oracle_config_from(PathConfig())
+    with torch.inference_mode():
+        ref, _ = tc.unet_forward(sd, oc, x[:nz * p * p], t[:nz], rna[:nz * p * p], p, p)
+    got = big[:nz * P * P].cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    mx = (got - ref).abs().max().item()
+    print(util.report(f"tile {dtype}", got, ref), "rel_l2=%.3e" % rel)
+    assert rel < TILE_TOL[dtype][0] and mx < TILE_TOL[dtype][1], (dtype, rel, mx)
+    if dtype != "f32":
+        _M.pop(dtype, None)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_forward_does_not_read_uninitialised_workspace(dtype):
+    """The caller-provided workspace is never assumed to be zero: a forward on a workspace poisoned with 0xFF bytes
+    (fp32 / bf16 / fp16 NaN patterns) returns the bits of a forward on a zeroed workspace.  (Every channel-pad slot,
+    halo cell and pair-padding block a kernel reads is written by its producer first.)"""
+    m = model(dtype)
+    for b, p1, p2 in ((2, 2, 2), (1, 3, 4)):
+        ne = b * p1 * p2
+        x = synth.normal(f"poison/x{b}{p1}", (ne, 4, 64, 64), 9).to(DEV)
+        rna = synth.gene_counts(f"poison/r{b}{p1}", (ne, 4, 4, 2000), 9).to(DEV)
+        t = torch.tensor([77 + 400 * i for i in range(b)], dtype=torch.long, device=DEV)
+        kw = dict(x=x, t=t, rna=rna, imgs=torch.empty((b, 4, 64 * (p1 - 1), 64 * (p2 - 1)), device="meta"), patch_size=64,
+                  want_pred2=True)
+        m(**kw)                                            # sizes the workspace
+        m._ws.fill_(0xFF)
+        a = m(**kw)
+        m._ws.zero_()
+        c = m(**kw)
+        assert torch.isfinite(a.pred).all() and torch.isfinite(a.pred2).all(), dtype
+        assert torch.equal(a.pred, c.pred) and torch.equal(a.pred2, c.pred2), dtype
+    if dtype != "f32":
+        _M.pop(dtype, None)
 
 
 @pytest.mark.parametrize("dtype,tol", [("bf16", 6e-3), ("f16", 8e-4)])

@@ -118,15 +118,19 @@ BF16_CASES = [(2, 16, 64, 8), (17, 24, 128, 8), (3, 13, 40, 8), (9, 229, 512, 8)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,S", BF16_CASES)
-def test_conv27_bf16_exact_integers(N, Cin, Cout, S):
-    """Small integers are exact in bf16 and their products/sums exact in fp32: bit-exact check of the
-    bf16 MFMA kernel's fragment layout, pair padding, slot swizzle and tiling."""
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv27_bf16_exact_integers(N, Cin, Cout, S, waves, dtype):
+    """Small integers are exact in bf16 / fp16 and their products/sums exact in fp32: bit-exact check of the
+    16-bit MFMA kernel's fragment layout, pair padding, slot swizzle and tiling -- in BOTH workgroup forms (the launcher
+    picks 4 waves for grids that would leave CUs idle and 8 waves otherwise; every case here is forced through each)
+    and both element types."""
     x = util.rand_int((N, Cin, 2, S, S), -3, 3, 41)
     w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 42)
     b = util.rand_int((Cout,), -4, 4, 43)
     ref = F.conv3d(x, w, b, padding=1)
-    got, raw = util.conv27_bf16(x.to(DEV), w, b)
-    assert torch.equal(got.cpu(), ref), util.report("conv27 bf16", got, ref)
+    got, raw = util.conv27_bf16(x.to(DEV), w, b, dtype, waves)
+    assert torch.equal(got.cpu(), ref), util.report("conv27 " + dtype, got, ref)
     if Cout % 8:
         assert float(raw[:, -1, ..., Cout % 8:].abs().max()) == 0.0
 
@@ -147,14 +151,44 @@ def test_conv27_bf16_random_vs_bf16_rounded_reference():
 
 @pytest.mark.parametrize("N,Cin,Cout,Z,S", [(2, 229, 1792, 2, 8), (1, 64, 256, 2, 16), (3, 13, 40, 2, 8), (1, 96, 64, 2, 64),
                                             (5, 512, 2048, 2, 8), (2, 1253, 512, 2, 8), (7, 128, 64, 2, 16)])
-def test_conv1_bf16_exact_integers(N, Cin, Cout, Z, S):
-    """bf16 Linear / 1x1 conv incl. ragged channel-pair stages and ragged voxel tiles."""
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv1_bf16_exact_integers(N, Cin, Cout, Z, S, waves, dtype):
+    """16-bit Linear / 1x1 conv incl. ragged channel-pair stages and ragged voxel tiles, in both workgroup forms
+    (two co-resident 4-wave workgroups per CU -- the default -- and one 8-wave workgroup) and both element types."""
     x = util.rand_int((N, Cin, Z, S, S), -3, 3, 51)
     w = util.rand_int((Cout, Cin, 1, 1, 1), -2, 2, 52)
     b = util.rand_int((Cout,), -4, 4, 53)
     ref = F.conv3d(x, w, b)
-    got, _ = util.conv1_bf16(x.to(DEV), w, b)
-    assert torch.equal(got.cpu(), ref), util.report("conv1 bf16", got, ref)
+    got, _ = util.conv1_bf16(x.to(DEV), w, b, False, dtype, waves)
+    assert torch.equal(got.cpu(), ref), util.report("conv1 " + dtype, got, ref)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,S,per_image", [(5, 24, 64, 8, 2), (3, 96, 128, 16, 1), (2, 40, 64, 32, 2), (1, 16, 128, 64, 1),
+                                                    (17, 13, 128, 8, 4)])
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv27_fused_norm_modulate_silu_epilogue(N, Cin, Cout, S, per_image, waves, dtype):
+    """The ResBlock mid-section fused into the first conv's epilogue (Cout <= 128: one workgroup holds every cout of its
+    voxels): conv + bias -> RMSNorm(C) * w -> x(1 + scale) + shift -> SiLU -> 16-bit (model/MBAblocks.py:196-203,356-367).
+    Integer operands make the conv sum exact, so the only difference to the fp32 torch reference is the final rounding
+    to the 16-bit type (half an ulp) plus fp32 rounding of the norm (1e-6 relative)."""
+    g = torch.Generator().manual_seed(61)
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 61)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 62)
+    b = util.rand_int((Cout,), -4, 4, 63)
+    nimg = (N + per_image - 1) // per_image
+    nw = torch.rand(Cout, generator=g) + 0.5
+    sc, sh = torch.randn((nimg, Cout), generator=g) * 0.3, torch.randn((nimg, Cout), generator=g) * 0.3
+    v = F.conv3d(x, w, b, padding=1)
+    img = torch.arange(N) // per_image
+    ref = v * torch.rsqrt(v.pow(2).mean(1, keepdim=True) + 1e-6) * nw.view(1, -1, 1, 1, 1)
+    ref = ref * (1 + sc[img].view(N, Cout, 1, 1, 1)) + sh[img].view(N, Cout, 1, 1, 1)
+    ref = ref * torch.sigmoid(ref)
+    got = util.conv27_fused(x.to(DEV), w, b, nw, sc, sh, per_image, dtype, waves).cpu()
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11
+    err = ((got - ref).abs() / (ref.abs() * ulp + 1e-4)).max().item()
+    assert err <= 1.01, (err, util.report("fused " + dtype, got, ref))
 
 
 # ---- windowed cross-attention core -------------------------------------------------------------------

@@ -45,6 +45,32 @@ def test_tile_sweep_hip_vs_oracle():
     assert d.max() <= 2e-3 and d.mean() <= 2e-5, util.report("sweep", got, ref)
 
 
+# (max, mean) bounds on |state - oracle sweep| after the two DDIM steps; the state is fp16-rounded after every step, x0 is
+# clamped to [-1, 1] and eps errors enter x0 with a factor sqrt(1/abar - 1) ~ 3.4 at t = 500 (16-bit eps errors: bf16
+# ~2e-3 absolute, f16 ~3e-4)
+SWEEP16_TOL = {"bf16": (0.15, 6e-3), "f16": (0.03, 1e-3)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_tile_sweep_16bit_whole_brain_layout_vs_oracle(dtype):
+    """BASELINE configs[3] in miniature: the tile sweep in the whole-brain configuration -- 16-bit UNet arithmetic
+    (bf16 as the config names it, f16 as the reference's autocast runs it) and ONE float16 state canvas -- against the
+    sweep driven by the fp32 CPU oracle (test_brn.py:174-226 per tile, :232-255 per step)."""
+    cfg = PathConfig(compute_dtype=dtype)
+    sd = util.state_dict(cfg)
+    genes = synthetic_gene_provider(cfg, total_slc=SLC)
+    kw = dict(hst=256, wst=512, hnm=2, wnm=1, total_epochs=T, total_slc=SLC)
+    ref = TileSweep(cfg, OracleSampler(cfg, sd), None, genes, device="cpu", **kw).test()
+    model = BeatGANsUNetModel(cfg, DEV).load_state_dict(sd)
+    sw = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, device=DEV, batch_tiles=1, state="fp16", **kw)
+    got = sw.test()
+    assert got.dtype == torch.float16 and got.shape == (SLC * 2, 512, 256) and sw.nxt is None
+    d = (got.float().cpu() - ref).abs()
+    print(util.report(f"sweep {dtype}", got, ref))
+    assert d.max() <= SWEEP16_TOL[dtype][0] and d.mean() <= SWEEP16_TOL[dtype][1], util.report("sweep " + dtype, got, ref)
+    assert float(got.float().abs().max()) <= 1.0 + 1e-3          # last DDIM step: the clamped x0 prediction
+
+
 def test_tile_sweep_single_fp16_canvas_equals_two_canvas_state():
     """state='fp16' (the whole-brain memory layout: one float16 canvas, rows committed one row late) on the GPU
     with the HIP model: bit-identical to the default two-canvas fp32 state."""

@@ -170,3 +170,11 @@ def test_run_batch_layout_maps_other_z_vs_reference(z):
     d = rb["saved_digest"]
     assert torch.equal(f[torch.tensor(d["idx"])].double(), torch.tensor(d["val"], dtype=torch.float64))
     assert abs(float(f.double().mean()) - d["mean"]) <= 1e-9
+
+
+def test_sample_rejects_unclamped_sampling():
+    """clip_denoised=False used to be accepted and silently ignored (the step kernel always clamps x0)."""
+    from teramind_amd.diffusion import SpacedDiffusionBeatGans
+    smp = SpacedDiffusionBeatGans(15, "ddim")
+    with pytest.raises(NotImplementedError):
+        smp.sample(model=None, shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), clip_denoised=False)

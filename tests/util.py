@@ -59,26 +59,45 @@ def conv_mfma(x, w, b, ksize, variant=0, zmode=0, up2=False):
     return from_cb8(yc, Cout), yc
 
 
-def conv27_bf16(x, w, b):
-    """x NCDHW cuda (Z == 2); rounds x (device) and w (host) to bf16, fp32 accumulate."""
+H16 = {"bf16": (1, torch.bfloat16), "f16": (2, torch.float16)}
+
+
+def conv27_bf16(x, w, b, dtype="bf16", waves=0):
+    """x NCDHW cuda (Z == 2); rounds x (device) and w (host) to the 16-bit `dtype`, fp32 accumulate.
+    waves: 0 = the launcher's choice, 4 / 8 = force that workgroup form."""
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
     xc = to_cb8(x)
     yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
     wh, bh = w.contiguous().float(), b.contiguous().float()
     _lib.check(_lib.lib().tm_op_conv27_bf16(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
-                                            N, Cin, Cout, S, _lib.current_stream_ptr()), "tm_op_conv27_bf16")
+                                            N, Cin, Cout, S, H16[dtype][0], waves, _lib.current_stream_ptr()), "tm_op_conv27_bf16")
     return from_cb8(yc, Cout), yc
 
 
-def conv1_bf16(x, w, b, gelu=False):
+def conv27_fused(x, w, b, norm_w, scale, shift, per_image, dtype="bf16", waves=0):
+    """3x3x3 conv + fused RMSNorm(C) * norm_w -> (1 + scale) + shift -> SiLU epilogue; returns the 16-bit result as
+    fp32 NCDHW.  scale / shift: [ceil(N / per_image), Cout] host tensors."""
+    N, Cin, Z, S, _ = x.shape
+    Cout = w.shape[0]
+    xc = to_cb8(x)
+    a2 = torch.zeros((N, Cout // 8, Z, S, S, 8), dtype=H16[dtype][1], device=x.device)
+    hs = [t.contiguous().float() for t in (w, b, norm_w, scale, shift)]
+    _lib.check(_lib.lib().tm_op_conv27_fused(_lib.ptr(xc), *[C.c_void_p(t.data_ptr()) for t in hs], _lib.ptr(a2),
+                                             N, Cin, Cout, S, per_image, H16[dtype][0], waves, _lib.current_stream_ptr()),
+               "tm_op_conv27_fused")
+    return from_cb8(a2.float(), Cout)
+
+
+def conv1_bf16(x, w, b, gelu=False, dtype="bf16", waves=0):
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
     xc = to_cb8(x)
     yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
     wh, bh = w.contiguous().float(), b.contiguous().float()
     _lib.check(_lib.lib().tm_op_conv1_bf16(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
-                                           N, Cin, Cout, Z, S, int(gelu), _lib.current_stream_ptr()), "tm_op_conv1_bf16")
+                                           N, Cin, Cout, Z, S, int(gelu), H16[dtype][0], waves, _lib.current_stream_ptr()),
+               "tm_op_conv1_bf16")
     return from_cb8(yc, Cout), yc
 
 

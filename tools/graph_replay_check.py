@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""One-shot diagnosis of the round-1 observation "a replayed HIP-graph capture of the forward was not bit-stable against
+the eager run".  For each arithmetic type: eager forward twice (bit-equal?), capture ONE forward into a graph
+(torch.cuda.CUDAGraph on a side stream; every library launch goes to torch's current stream), replay it several times
+with (a) untouched buffers, (b) the workspace poisoned with 0xFF bytes before the replay, (c) new input VALUES copied
+into the captured input buffers, and compare with eager runs on the same values.  With TM_DEBUG_DIR-style taps not being
+capturable, the first differing block is found by capturing the forward with `pred2` and comparing both outputs.
+Prints one JSON line; nothing is looped until it fails."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import teramind_amd  # noqa: F401
+    from teramind_amd import synth
+    from teramind_amd.config import PathConfig
+    from teramind_amd.unet import BeatGANsUNetModel
+    from teramind_amd.weights import hashed_state_dict
+    dev = torch.device("cuda:0")
+    out = {}
+    for dtype in ("f32", "bf16", "f16"):
+        cfg = PathConfig(compute_dtype=dtype)
+        m = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
+        b, p = 2, 2
+        ne = b * p * p
+        xs = [synth.normal(f"g/x{k}", (ne, 4, 64, 64), 3).to(dev) for k in range(2)]
+        rs = [synth.gene_counts(f"g/r{k}", (ne, 4, 4, 2000), 3).to(dev) for k in range(2)]
+        ts = [torch.tensor([77, 877], device=dev), torch.tensor([500, 3], device=dev)]
+        shp = torch.empty((b, 4, 64, 64), device="meta")
+        eager = []
+        for k in range(2):
+            a = m(x=xs[k], t=ts[k], rna=rs[k], imgs=shp, patch_size=64, want_pred2=True)
+            c = m(x=xs[k], t=ts[k], rna=rs[k], imgs=shp, patch_size=64, want_pred2=True)
+            torch.cuda.synchronize()
+            eager.append((a.pred.clone(), a.pred2.clone()))
+            out[f"{dtype}.eager_repeat_equal.{k}"] = bool(torch.equal(a.pred, c.pred) and torch.equal(a.pred2, c.pred2))
+        # static input buffers + capture
+        sx, st, sr = xs[0].clone(), ts[0].clone(), rs[0].clone()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(x=sx, t=st, rna=sr, imgs=shp, patch_size=64, want_pred2=True)          # warm on the side stream
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                res = m(x=sx, t=st, rna=sr, imgs=shp, patch_size=64, want_pred2=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        def replay():
+            g.replay()
+            torch.cuda.synchronize()
+            return res.pred.clone(), res.pred2.clone()
+
+        def cmp(got, ref):
+            return {"pred_equal": bool(torch.equal(got[0], ref[0])), "pred2_equal": bool(torch.equal(got[1], ref[1])),
+                    "pred_maxdiff": float((got[0] - ref[0]).abs().max()), "pred2_maxdiff": float((got[1] - ref[1]).abs().max())}
+
+        out[f"{dtype}.replay1_vs_eager"] = cmp(replay(), eager[0])
+        out[f"{dtype}.replay2_vs_eager"] = cmp(replay(), eager[0])
+        m._ws.fill_(0xFF)
+        out[f"{dtype}.replay_poisoned_ws_vs_eager"] = cmp(replay(), eager[0])
+        sx.copy_(xs[1]); st.copy_(ts[1]); sr.copy_(rs[1])
+        out[f"{dtype}.replay_new_inputs_vs_eager"] = cmp(replay(), eager[1])
+        del g, m
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

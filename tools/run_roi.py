@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""End-to-end rehearsal of the test_brn flow on one GPU with synthetic genes and hashed weights: a full T-step
-DDIM sweep of an hnm x wnm tile ROI through the product classes (TileSweep + SpacedDiffusionBeatGans +
-BeatGANsUNetModel), then save_step -> stitch_dir -> slice images, exactly the sequence
-`python -m test_brn ...` + `python -m infer_brn ...` performs in the reference.  Prints one JSON line with the
-measured wall time (this is a measurement at the stated ROI size, not an extrapolation)."""
+"""End-to-end run of the test_brn flow with synthetic genes and hashed weights: a full T-step DDIM sweep of an
+hnm x wnm tile ROI through the product classes (launch.run_sweep -> TileSweep + SpacedDiffusionBeatGans +
+BeatGANsUNetModel), then save_step -> stitch_dir -> slice images, exactly the sequence `python -m test_brn ...` +
+`python -m infer_brn ...` performs in the reference (test_brn.py:232-273, infer_brn.py:57-105).
+`--gpus N` starts N rank processes (one per GPU; rows of the tile grid are split over them, RCCL strip exchange per
+step).  `--gene_dir` reads the reference's on-disk gene tiles ('{r0}_..._{C1}.npz' COO archives, made by
+`--make_genes` from the synthetic generator) through brain.GeneTileDir: the COO arrays stay resident and
+tm_gene_tile_dense re-densifies them for every tile call.  Prints one JSON line with the measured wall time (a
+measurement at the stated ROI size, not an extrapolation)."""
 import argparse
 import json
 import os
@@ -15,67 +19,109 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--hnm", type=int, default=4)
-    ap.add_argument("--wnm", type=int, default=8)
-    ap.add_argument("--tot_epoch", type=int, default=15)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16")
-    ap.add_argument("--state", choices=["fp32x2", "fp16"], default="fp16")
-    ap.add_argument("--out_dir", default=None)
-    args = ap.parse_args()
+def make_gene_dir(gdir, hnm, wnm, nnz, hst=256, wst=256):
+    """Synthetic COO gene tiles in the reference's on-disk format (utils/MBADataset_tst.py:65-79 reads them)."""
+    import numpy as np
+    from teramind_amd import formats
+    os.makedirs(gdir, exist_ok=True)
+    for r in range(hst // 256, hst // 256 + hnm):
+        for c in range(wst // 256, wst // 256 + wnm):
+            rng = np.random.default_rng(1_000_003 * r + c)
+            shape = (512, 512, 50 * 500)
+            crd = np.stack([rng.integers(0, 512, nnz), rng.integers(0, 512, nnz), rng.integers(0, shape[2], nnz)]).astype(np.int64)
+            data = rng.integers(1, 4, nnz).astype(np.uint16)
+            v = (r * 256, r * 256 + 256, c * 256, c * 256 + 256, r * 256 - 128, r * 256 + 384, c * 256 - 128, c * 256 + 384)
+            formats.write_gene_npz(os.path.join(gdir, "_".join(map(str, v)) + ".npz"), data, crd, shape)
+
+
+def worker(args):
     import numpy as np
     import torch
     import teramind_amd  # noqa: F401
-    from teramind_amd import stitch
-    from teramind_amd.brain import TileSweep, synthetic_gene_provider
+    from teramind_amd import launch, stitch
+    from teramind_amd.brain import GeneTileDir, device_gene_provider
     from teramind_amd.config import PathConfig
     from teramind_amd.diffusion import SpacedDiffusionBeatGans
     from teramind_amd.unet import BeatGANsUNetModel
     from teramind_amd.weights import hashed_state_dict
 
-    dev = "cuda:0"
+    rank, local_rank, world = launch.dist_env()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    launch.init_distributed("nccl", dev)
     cfg = PathConfig(compute_dtype=args.dtype)
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
-    host_genes, resident = synthetic_gene_provider(cfg, total_slc=50), {}
-
-    def genes(row, col):
-        if (row, col) not in resident:
-            resident[(row, col)] = host_genes(row, col).to(dev)
-        return resident[(row, col)]
-
     T = args.tot_epoch
-    sw = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, hst=256, wst=256, hnm=args.hnm, wnm=args.wnm,
-                   total_epochs=T, total_slc=50, device=dev, batch_tiles=1, init="device", state=args.state)
-    for r in range(args.hnm):
-        for c in range(args.wnm):
-            genes(1 + r, 1 + c)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    per_step = []
-    while sw.epoch < T:
-        t1 = time.perf_counter()
-        sw.step()
-        torch.cuda.synchronize()
-        per_step.append(time.perf_counter() - t1)
-        print(f"[run_roi] step {sw.epoch}/{T}: {per_step[-1]:.2f} s", file=sys.stderr, flush=True)
-    sweep_s = time.perf_counter() - t0
+    if args.gene_dir:
+        genes = GeneTileDir(args.gene_dir, cfg, dev, total_slc=50, keep_resident=True)
+    else:
+        genes = device_gene_provider(cfg, dev)
+
+    def on_step(sw, s):
+        if rank == 0:
+            print(f"[run_roi] step {sw.epoch}/{T}: {s:.2f} s", file=sys.stderr, flush=True)
+
+    t_load = time.perf_counter()
+    res = launch.run_sweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, hnm=args.hnm, wnm=args.wnm, total_epochs=T,
+                           steps=T, warmup=0, device=dev, batch_tiles=args.batch_tiles, init=args.init, state=args.state,
+                           on_step=on_step)
+    sw, sweep_s, per_step = res["sweep"], res["dt"], res["step_s"]
     st = sw.local_state()
     out_dir = args.out_dir or tempfile.mkdtemp(prefix="roi_")
     t2 = time.perf_counter()
     d = sw.save_step(os.path.join(out_dir, "timestep"))
-    mosaic = stitch.stitch_dir(d, 256, 256, args.hnm, args.wnm, 50, slices=[0, 1, 48, 49])
-    stitch.save_slices(mosaic, os.path.join(out_dir, "gen"), names=[0, 1, 48, 49])
-    io_s = time.perf_counter() - t2
-    same = bool(np.array_equal(mosaic, stitch.stitch_state(st, 50, [0, 1, 48, 49]).cpu().numpy()))
-    tiles = args.hnm * args.wnm
-    print(json.dumps({"what": "full ROI sweep, measured", "dtype": args.dtype, "state": args.state, "tiles": tiles, "T": T,
-                      "sweep_s": round(sweep_s, 2), "s_per_tile_step": round(sweep_s / (tiles * T), 4),
-                      "interior_patch_steps_per_s": round(400 * tiles * T / sweep_s, 1),
-                      "first_step_s": round(per_step[0], 2), "last_step_s": round(per_step[-1], 2),
-                      "save_and_stitch_s": round(io_s, 2), "stitch_from_files_equals_resident": same,
-                      "state_finite": bool(torch.isfinite(st.float()).all()), "state_absmax": float(st.float().abs().max()),
-                      "state_std": float(st.float().std())}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    io_save = time.perf_counter() - t2
+    if rank == 0:
+        t3 = time.perf_counter()
+        mosaic = stitch.stitch_dir(d, 256, 256, args.hnm, args.wnm, 50, slices=[0, 1, 48, 49])
+        stitch.save_slices(mosaic, os.path.join(out_dir, "gen"), names=[0, 1, 48, 49])
+        io_s = io_save + time.perf_counter() - t3
+        same = None
+        if world == 1:
+            same = bool(np.array_equal(mosaic, stitch.stitch_state(st, 50, [0, 1, 48, 49]).cpu().numpy()))
+        tiles = args.hnm * args.wnm
+        print(json.dumps({"what": "full ROI sweep, measured", "dtype": args.dtype, "state": args.state, "tiles": tiles, "T": T,
+                          "n_gpus": world, "genes": "on-disk COO .npz via GeneTileDir + tm_gene_tile_dense" if args.gene_dir else "synthetic, device resident",
+                          "init": args.init, "batch_tiles": args.batch_tiles,
+                          "sweep_s": round(sweep_s, 2), "sweep_min": round(sweep_s / 60, 2), "s_per_tile_step": round(sweep_s * world / (tiles * T), 4),
+                          "interior_patch_steps_per_s": round(400 * tiles * T / sweep_s, 1),
+                          "first_step_s": round(per_step[0], 2), "last_step_s": round(per_step[-1], 2),
+                          "exchange_ms_per_step": round(res["exchange_ms_per_step"], 3),
+                          "save_and_stitch_s": round(io_s, 2), "stitch_from_files_equals_resident": same,
+                          "state_finite": bool(torch.isfinite(st.float()).all()), "state_absmax": float(st.float().abs().max()),
+                          "state_std": float(st.float().std())}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--hnm", type=int, default=4)
+    ap.add_argument("--wnm", type=int, default=8)
+    ap.add_argument("--tot_epoch", type=int, default=15)
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="bf16")
+    ap.add_argument("--state", choices=["fp32x2", "fp16"], default="fp16")
+    ap.add_argument("--init", choices=["device", "reference"], default="device",
+                    help="reference = the LCG-seeded CPU mt19937 noise of MBADataset_tst (slow: ~0.1 s per tile)")
+    ap.add_argument("--batch_tiles", type=int, default=1)
+    ap.add_argument("--gene_dir", default=None)
+    ap.add_argument("--make_genes", type=int, default=0, help="write synthetic COO gene tiles with this many entries each into --gene_dir first")
+    ap.add_argument("--out_dir", default=None)
+    args = ap.parse_args()
+    from teramind_amd import launch
+    if args.gene_dir and args.make_genes and not launch.launched_as_rank():
+        t0 = time.perf_counter()
+        make_gene_dir(args.gene_dir, args.hnm, args.wnm, args.make_genes)
+        print(f"[run_roi] wrote {args.hnm * args.wnm} gene tiles in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    if args.gpus > 1 and not launch.launched_as_rank():
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    worker(args)
 
 
 if __name__ == "__main__":
