@@ -199,9 +199,13 @@ int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host
 
 /* 16-bit variant of the 3x3x3 pad-1 conv (Z == 2): x fp32 CB8 is rounded to `dtype` (TM_DTYPE_BF16 | TM_DTYPE_F16, RNE) on
  * the device, w rounded on the host; fp32 accumulate, fp32 CB8 output.  waves: 0 = the launcher's choice, 4 | 8 = force
- * the 4-wave (128 x 256 / 64 x 512 tile) or 8-wave (128 x 512 / 64 x 1024) workgroup form. */
+ * the 4-wave (128 x 256 / 64 x 512 tile) or 8-wave (128 x 512 / 64 x 1024) workgroup form.
+ * res_h16 (nullable): 16-bit CB8 residual [N][ceil(Cout/8)][2][S][S][8] added in fp32 before the final rounding;
+ * y_h16 (nullable): write the result as a 16-bit CB8 tensor of that shape INSTEAD of y_cb8 (the 16-bit activation
+ * stream of the model: block outputs and residuals are 16-bit tensors, as under the reference's fp16 autocast). */
 int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
-                      int N, int Cin, int Cout, int S, int dtype, int waves, void* stream);
+                      int N, int Cin, int Cout, int S, int dtype, int waves, const void* res_h16, void* y_h16,
+                      void* stream);
 
 /* The same conv with the ResBlock mid-section fused into its epilogue (Cout in {64, 128}): out_layers[0]
  * RMSNorm(C) * norm_w -> x * (1 + scale) + shift -> SiLU (model/MBAblocks.py:196-203,356-367), written as the 16-bit CB8
@@ -212,9 +216,11 @@ int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const void* bias_h
                        int S, int per_image, int dtype, int waves, void* stream);
 
 /* 16-bit 1x1x1 conv / Linear over '(z h w) c' tokens (x and w rounded to `dtype`, fp32 accumulate).  waves: 0 | 4 | 8
- * as above (two co-resident 4-wave workgroups per CU, or one 8-wave workgroup). */
+ * as above (two co-resident 4-wave workgroups per CU, or one 8-wave workgroup).  Epilogue (model/MBAblocks.py:486-489):
+ * y = res + gate * gelu?(W x + b) with optional 16-bit CB8 `res_h16` / `gate_h16` and 16-bit output `y_h16`. */
 int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
-                     int N, int Cin, int Cout, int Z, int S, int gelu, int dtype, int waves, void* stream);
+                     int N, int Cin, int Cout, int Z, int S, int gelu, int dtype, int waves, const void* res_h16,
+                     const void* gate_h16, void* y_h16, void* stream);
 
 /* Windowed gene-patch cross attention core (model/MBAblocks.py:551-601 between the q/k/v Linears and proj):
  * q, k, v fp32 CB8 [N, C, Z, S, S]; qw, kw: device fp32 [C] (q_norm / k_norm weights).

@@ -60,9 +60,9 @@ SIGNATURES = {
     "tm_op_to_cb8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "tm_op_from_cb8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "tm_op_conv_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
-    "tm_op_conv27_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "tm_op_conv27_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 3),
     "tm_op_conv27_fused": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
-    "tm_op_conv1_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "tm_op_conv1_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4),
     "tm_op_window_attn": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "tm_op_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
 }

@@ -96,30 +96,118 @@ __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) ss[mt] += red[((wm * 4 + mt) * 2 + (wn ^ 1)) * 32 + i32];
   }
-  typedef h16_t bf16x4_t __attribute__((ext_vector_type(4)));
+  // apply pass with 16-byte stores: one v_permlane32_swap per register gives lane h = 0 the whole CB8 block 2q and lane
+  // h = 1 the whole block 2q + 1 of its voxel (see conv_epilogue_h16 below)
+  typedef h16_t h16x8_t __attribute__((ext_vector_type(8)));
+  float rstd[4];
+  long mo[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    if (ooff[mt] < 0) continue;
-    const float rstd = 1.0f / sqrtf(ss[mt] * ah.inv_c + TM_EPS);
-    const long mo = (long)(on[mt] / ah.per_image) * ah.mod_stride;
+    rstd[mt] = 1.0f / sqrtf(ss[mt] * ah.inv_c + TM_EPS);
+    mo[mt] = (long)(on[mt] / ah.per_image) * ah.mod_stride;
+  }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cob = wn * 8 + ct * 4 + g;
-        const int c0 = cob * 8 + 4 * h;
-        const f32x4 w4 = *(const f32x4*)(ah.norm_w + c0);
-        const f32x4 sc = *(const f32x4*)(ah.mod_scale + mo + c0), sh = *(const f32x4*)(ah.mod_shift + mo + c0);
-        bf16x4_t ob;
+    for (int q = 0; q < 2; ++q) {
+      const int cob = wn * 8 + ct * 4 + 2 * q + h;
+      const f32x4 w0 = *(const f32x4*)(ah.norm_w + cob * 8), w1 = *(const f32x4*)(ah.norm_w + cob * 8 + 4);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = w4[j] * (acc[ct][mt][4 * g + j] * rstd);
-          v = v * (1.0f + sc[j]) + sh[j];
-          ob[j] = (h16_t)silu_f(v);
+          // (by value first: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 on this clang)
+          const float xq = acc[ct][mt][8 * q + j], yq = acc[ct][mt][8 * q + 4 + j];
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(xq), __float_as_uint(yq), false, false);
+          v[j] = __uint_as_float(r[0]);
+          v[4 + j] = __uint_as_float(r[1]);
         }
-        *(bf16x4_t*)(ah.a2 + (long)on[mt] * ah.a2_nstride + (long)cob * a.y_plane + ooff[mt] + 4 * h) = ob;
-        __builtin_amdgcn_sched_barrier(0);          // keep the per-(cout block) loads from being hoisted en masse
+        if (ooff[mt] < 0) continue;
+        const float* scp = ah.mod_scale + mo[mt] + cob * 8;
+        const float* shp = ah.mod_shift + mo[mt] + cob * 8;
+        const f32x4 sc0 = *(const f32x4*)scp, sc1 = *(const f32x4*)(scp + 4), sh0 = *(const f32x4*)shp, sh1 = *(const f32x4*)(shp + 4);
+        h16x8_t ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a0 = w0[j] * (v[j] * rstd[mt]), a1 = w1[j] * (v[4 + j] * rstd[mt]);
+          a0 = a0 * (1.0f + sc0[j]) + sh0[j];
+          a1 = a1 * (1.0f + sc1[j]) + sh1[j];
+          ob[j] = (h16_t)silu_f(a0);
+          ob[4 + j] = (h16_t)silu_f(a1);
+        }
+        *(h16x8_t*)(ah.a2 + (long)on[mt] * ah.a2_nstride + (long)cob * a.y_plane + ooff[mt]) = ob;
       }
+      __builtin_amdgcn_sched_barrier(0);          // keep the per-(cout block) loads from being hoisted en masse
+    }
+}
+
+// Epilogue of the 16-bit kernels with 16-byte global accesses.  After the MFMAs lane (i32, h) holds, per accumulator quad
+// g, couts 8g + 4h .. 8g + 4h + 3 of its voxel: HALF of a CB8 channel block, the other half sits in lane i32 + 32.  One
+// v_permlane32_swap per register hands lane h = 0 the whole block 2q and lane h = 1 the whole block 2q + 1 (h = 0 gives its
+// quad of block 2q + 1 away and receives the partner's quad of block 2q), so that a 16-bit CB8 entry (8 couts = 16 bytes)
+// is read (gate, residual) and written by ONE lane: half the memory instructions of the 8-byte-per-lane form, each at the
+// full 16-byte width.  Arithmetic and its order are those of conv_epilogue: (acc + bias) -> GELU -> * gate -> res + .
+__device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&acc)[2][4], int cob0, int h,
+                                                  const int (&on)[4], const int (&ooff)[4]) {
+  typedef h16_t h16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int cob = cob0 + ct * 4 + 2 * q + h;            // the block this lane owns after the swap
+      const bool cob_ok = cob < a.Cob;
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (cob_ok) { b0 = *(const f32x4*)(a.bias + (long)cob * 8); b1 = *(const f32x4*)(a.bias + (long)cob * 8 + 4); }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // (by value first: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 on this clang)
+          const float xq = acc[ct][mt][8 * q + j], yq = acc[ct][mt][8 * q + 4 + j];
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(xq), __float_as_uint(yq), false, false);
+          o[j] = __uint_as_float(r[0]) + b0[j];
+          o[4 + j] = __uint_as_float(r[1]) + b1[j];
+        }
+        if (!cob_ok || ooff[mt] < 0) continue;
+        if (a.flags & EPI_GELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = gelu_tanh_f(o[j]);
+        }
+        const long pl = (long)cob * a.y_plane + ooff[mt];
+        if (a.gate_h) {
+          const h16x8 gb = *(const h16x8*)(a.gate_h + (long)on[mt] * a.gate_h_nstride + pl);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] *= (float)gb[j];
+        } else if (a.gate) {
+          const float* gp = a.gate + (long)on[mt] * a.gate_nstride + pl;
+          const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[j] *= g0[j]; o[4 + j] *= g1[j]; }
+        }
+        if (a.res_h) {
+          const h16x8 rb = *(const h16x8*)(a.res_h + (long)on[mt] * a.res_h_nstride + pl);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (float)rb[j] + o[j];
+        } else if (a.res) {
+          const float* rp = a.res + (long)on[mt] * a.res_nstride + pl;
+          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[j] = r0[j] + o[j]; o[4 + j] = r1[j] + o[4 + j]; }
+        }
+        if (a.y_h) {
+          h16x8 ob;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ob[j] = (h16_t)o[j];
+          *(h16x8*)(a.y_h + (long)on[mt] * a.yh_nstride + pl) = ob;
+        } else {
+          float* yp = a.y + (long)on[mt] * a.y_nstride + pl;
+          *(f32x4*)yp = f32x4{o[0], o[1], o[2], o[3]};
+          *(f32x4*)(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+      }
+    }
   }
 }
 
@@ -303,7 +391,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
     __syncthreads();          // drains this wave's LDS-DMA (vmcnt) and fences the buffer swap
   }
   if (FUSE) fused_norm_epilogue<G::WNW>(ah, acc, wn, wm, i32, h, on, ooff, (float*)lds16);
-  else conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 2 * S);
+  else conv_epilogue_h16(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
 }
 
 // ---- 1x1x1 conv / Linear on '(z h w) c' tokens, bf16 operands (flat voxel tiles) -----------
@@ -439,7 +527,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail's dummy DMAs before the LDS is released
-  conv_epilogue<4>(a, acc, nt * G::WNW + wn, h, on, ooff, 0);
+  conv_epilogue_h16(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
 }
 
 
@@ -1014,6 +1102,7 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.gate_h = L.gate_h ? L.gate_h->p : nullptr; a.gate_h_nstride = L.gate_h ? L.gate_h->nstride : 0;
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = L.flags;
   a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
+  a.res_h = L.res_h ? L.res_h->p : nullptr; a.res_h_nstride = L.res_h ? L.res_h->nstride : 0;
   ah.fuse = 0;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
   if ((L.x.Cb & 1) || L.x.H != L.x.W || L.y.H != L.x.H || L.y.Z != L.x.Z || L.y.N != L.x.N || (L.flags & EPI_UP2))
@@ -1054,7 +1143,8 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
   a.gate = nullptr; a.gate_nstride = 0;
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = 0;
-  a.y_h = nullptr; a.yh_nstride = 0;
+  a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
+  a.res_h = L.res_h ? L.res_h->p : nullptr; a.res_h_nstride = L.res_h ? L.res_h->nstride : 0;
   ah.fuse = L.fuse_norm; ah.norm_w = L.norm_w; ah.mod_scale = L.mod_scale; ah.mod_shift = L.mod_shift;
   ah.mod_stride = L.mod_stride; ah.per_image = L.per_image; ah.inv_c = 1.0f / (float)L.Cout;
   ah.a2 = L.a2.p; ah.a2_nstride = L.a2.nstride;
@@ -1064,7 +1154,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   const int S = a.S, TN = conv_bf16_tn(L.Cout);
   a.ntile = (L.Cout + TN - 1) / TN;
   if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
-  if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res)) return hipErrorInvalidValue;
+  if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res || L.res_h)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
   static const int env27 = env_waves("TM_CONV27_WAVES");
   const int fw27 = L.force_waves ? L.force_waves : env27;

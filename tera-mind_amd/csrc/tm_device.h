@@ -67,6 +67,8 @@ struct ConvArgs {
   const uint16_t* gate_h = nullptr; // optional bf16 CB8 gate instead of `gate` (same plane geometry as y)
   long gate_h_nstride = 0;
   int Zin = 0, zoff = 0;            // conv3d NZI = 3: source plane = zo + zi + zoff, zero outside [0, Zin)
+  const uint16_t* res_h = nullptr;  // 16-bit kernels only: 16-bit CB8 residual instead of `res` (the 16-bit activation stream)
+  long res_h_nstride = 0;
 };
 
 // XCD-aware workgroup id (cdna guide T1): the dispatcher deals consecutive blockIdx round-robin over the 8 XCDs

@@ -73,8 +73,9 @@ struct ConvLaunchH {
   const TV* gate = nullptr;         // conv1 only
   const TVH* gate_h = nullptr;      // conv1 only: bf16 gate instead of `gate`
   int flags = 0;                    // conv1 only: EPI_GELU
-  uint16_t* y_h = nullptr;          // conv1 only: write bf16 CB8 INSTEAD of y (next Linear's input)
+  uint16_t* y_h = nullptr;          // write 16-bit CB8 INSTEAD of y (the 16-bit activation stream / next Linear's input)
   long yh_nstride = 0;
+  const TVH* res_h = nullptr;       // 16-bit CB8 residual instead of `res`
   // conv27 only, Cout in {64, 128}: fuse RMSNorm(C)*w -> x(1+scale)+shift -> SiLU into the epilogue and write
   // the bf16 tensor `a2` (the next conv's input) instead of y
   int fuse_norm = 0;
@@ -137,7 +138,8 @@ struct PrepLaunch {
   int pad_blocks = 0;               // extra all-zero channel blocks appended to the bf16 output (pair padding)
   uint16_t* raw_h = nullptr;        // bf16 instead of `raw` (input of the bf16 skip conv); same pad_blocks
   long raw_h_nstride = 0;
-  int h_f16 = 0;                    // the 16-bit tensors (out_h, raw_h, mod_*_h) are IEEE half instead of bf16
+  int h_f16 = 0;                    // the 16-bit tensors (out_h, raw_h, mod_*_h, sources with src_h) are IEEE half instead of bf16
+  int src_h = 0;                    // the SOURCES are 16-bit CB8 tensors (src[k].p reinterpreted; nstride in elements)
 };
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
 
@@ -160,7 +162,9 @@ struct DirectLaunch {
 hipError_t launch_conv_direct(const DirectLaunch& L, hipStream_t s);
 
 // stem: x NCHW '(s z) h w' [N][Cin*Z][S][S] -> y CB8; w [9][Cin][y.Cb*8]
-hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s);
+// y_h != null: write the 16-bit CB8 tensor (geometry of y, nstride in elements) instead of y
+hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s,
+                       uint16_t* y_h = nullptr, long yh_nstride = 0, int h_f16 = 0);
 // head: x CB8 (Cb blocks) -> y NCHW [N][Cout*Z][S][S]; w [9][x.Cb*8][8]
 hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s);
 

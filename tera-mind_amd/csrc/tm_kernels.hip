@@ -489,10 +489,29 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
   // this wave owns the virtual (concatenated) channel blocks gb = wv, wv + 4, wv + 8, ...
   const int cb0 = L.src[0].Cb, cb01 = cb0 + ((L.nsrc > 1) ? L.src[1].Cb : 0);
   const int cbtot = cb01 + ((L.nsrc > 2) ? L.src[2].Cb : 0);
-  auto src_ptr = [&](int gb, int sub) -> const float* {
+  // 8 channels of one voxel of the virtual (concatenated) block gb: fp32 sources (32 bytes) or, with src_h, 16-bit
+  // sources (16 bytes; offsets and strides are in elements either way)
+  auto load8 = [&](int gb, int sub, f32x4& a0, f32x4& a1) {
     const int k = (gb >= cb0) + (gb >= cb01);
     const int cb = gb - (k == 0 ? 0 : (k == 1 ? cb0 : cb01));
-    return L.src[k].p + soff[k][sub] + (long)cb * splane[k];
+    const long off = soff[k][sub] + (long)cb * splane[k];
+    if (L.src_h) {
+      const uint16_t* p = (const uint16_t*)L.src[k].p + off;
+      if (L.h_f16) {
+        typedef _Float16 f16x8_s __attribute__((ext_vector_type(8)));
+        const f16x8_s v = *(const f16x8_s*)p;
+        a0 = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        a1 = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+      } else {
+        typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+        const bf16x8_s v = *(const bf16x8_s*)p;
+        a0 = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        a1 = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+      }
+    } else {
+      const float* p = L.src[k].p + off;
+      a0 = *(const f32x4*)p; a1 = *(const f32x4*)(p + 4);
+    }
   };
   constexpr int NC = CACHED ? 8 : 1;
   f32x4 c0[NC], c1[NC];            // CACHED only (NSUB == 1)
@@ -510,8 +529,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         for (int i = 0; i < NC; ++i) {
           const int gb = wv + 4 * i;
           if (gb < cbtot) {
-            const float* p = src_ptr(gb, 0);
-            c0[i] = *(const f32x4*)p; c1[i] = *(const f32x4*)(p + 4);
+            load8(gb, 0, c0[i], c1[i]);
             ssq[0] += c0[i][0] * c0[i][0] + c0[i][1] * c0[i][1] + c0[i][2] * c0[i][2] + c0[i][3] * c0[i][3] +
                       c1[i][0] * c1[i][0] + c1[i][1] * c1[i][1] + c1[i][2] * c1[i][2] + c1[i][3] * c1[i][3];
           }
@@ -520,8 +538,8 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         for (int gb = wv; gb < cbtot; gb += 4) {
 #pragma unroll
           for (int sub = 0; sub < NSUB; ++sub) {
-            const float* p = src_ptr(gb, sub);
-            const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
+            f32x4 a0, a1;
+            load8(gb, sub, a0, a1);
             ssq[sub] += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] +
                         a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
           }
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
     for (int sub = 0; sub < NSUB; ++sub) {
       f32x4 a0, a1;
       if (CACHED) { a0 = c0[i]; a1 = c1[i]; }
-      else { const float* p = src_ptr(gb, sub); a0 = *(const f32x4*)p; a1 = *(const f32x4*)(p + 4); }
+      else load8(gb, sub, a0, a1);
       const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -757,6 +775,7 @@ struct StemArgs {
   const float* x; float* y; const float* w; const float* bias;   // w: [tap 9][ci][Cop]
   int N, Cin, Cout, Cop, Z, S;
   long y_nstride;
+  uint16_t* y_h; long yh_nstride; int h_f16;                     // 16-bit CB8 output instead of y (bf16, or fp16 with h_f16)
 };
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
   const int S = a.S;
@@ -785,6 +804,27 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
       }
     }
   }
+  if (a.y_h) {
+    uint16_t* hp = a.y_h + (long)n * a.yh_nstride + ((long)(z * S + y) * S + x) * 8;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      uint16_t* p = hp + (long)(cob0 + b) * vpn * 8;
+      if (a.h_f16) {
+        typedef _Float16 f16x8_o __attribute__((ext_vector_type(8)));
+        f16x8_o o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)acc[b * 8 + j];
+        *(f16x8_o*)p = o;
+      } else {
+        typedef __bf16 bf16x8_o __attribute__((ext_vector_type(8)));
+        bf16x8_o o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[b * 8 + j];
+        *(bf16x8_o*)p = o;
+      }
+    }
+    return;
+  }
   float* yp = a.y + (long)n * a.y_nstride + ((long)(z * S + y) * S + x) * 8;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
@@ -793,9 +833,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     *(f32x4*)(p + 4) = f32x4{acc[b * 8 + 4], acc[b * 8 + 5], acc[b * 8 + 6], acc[b * 8 + 7]};
   }
 }
-hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s) {
+hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s, uint16_t* y_h,
+                       long yh_nstride, int h_f16) {
   if (y.C % 32) return hipErrorInvalidValue;
-  StemArgs a{x, y.p, w, bias, y.N, Cin, y.C, y.Cb * 8, y.Z, y.H, y.nstride};
+  StemArgs a{x, y.p, w, bias, y.N, Cin, y.C, y.Cb * 8, y.Z, y.H, y.nstride, y_h, yh_nstride, h_f16};
   const long vox = (long)y.N * y.Z * y.H * y.W;
   hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((vox + 255) / 256), (unsigned)(y.C / 32)), dim3(256), 0, s, a);
   return hipGetLastError();

@@ -670,8 +670,24 @@ struct Ctx {
     t.p = (uint16_t*)alloc_f(((size_t)N * t.nstride + 1) / 2);
     return t;
   }
+  // Activation-stream tensor (block outputs, skips, RNA pyramid levels): fp32 CB8 in TM_DTYPE_F32; in the 16-bit modes
+  // the SAME geometry with 16-bit elements (the TV's `p` then points at uint16_t data and `nstride` counts elements).
+  TV tensor_s(int N, int C, int Z, int S) {
+    if (!is_h16(m->cfg.dtype)) return tensor(N, C, Z, S);
+    TV t;
+    t.N = N; t.C = C; t.Cb = (C + 7) / 8; t.Z = Z; t.H = S; t.W = S;
+    t.nstride = (long)t.Cb * t.plane();
+    t.p = alloc_f(((size_t)N * t.nstride + 1) / 2);
+    return t;
+  }
   void check(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
 };
+// 16-bit view of a stream tensor (16-bit modes only)
+static TVH as_h(const TV& t) {
+  TVH v;
+  v.p = (uint16_t*)t.p; v.N = t.N; v.C = t.C; v.Cb = t.Cb; v.Z = t.Z; v.H = t.H; v.W = t.W; v.nstride = t.nstride;
+  return v;
+}
 
 struct Src { TV t; bool collage; };
 
@@ -681,11 +697,23 @@ static const char* debug_dir() {
   static const char* d = getenv("TM_DEBUG_DIR");
   return (d && *d) ? d : nullptr;
 }
-static void dump_tv(Ctx& cx, const std::string& name, const TV& t) {
+static void dump_tv(Ctx& cx, const std::string& name, const TV& t_in) {
   if (cx.dry || !debug_dir()) return;
+  TV t = t_in;
   const size_t n = (size_t)t.N * t.C * t.Z * t.H * t.W;
   float* dev = nullptr;
+  float* f32copy = nullptr;
   if (hipMalloc((void**)&dev, n * sizeof(float)) != hipSuccess) return;
+  if (is_h16(cx.m->cfg.dtype)) {              // 16-bit stream tensor -> fp32 CB8 copy (prep kernel, no norm / act)
+    if (hipMalloc((void**)&f32copy, (size_t)t.N * t.nstride * sizeof(float)) != hipSuccess) { (void)hipFree(dev); return; }
+    PrepLaunch P;
+    P.nsrc = 1;
+    P.src[0].p = t.p; P.src[0].nstride = t.nstride; P.src[0].Cb = t.Cb;
+    P.N = t.N; P.Z = t.Z; P.S = t.H; P.src_h = 1; P.h_f16 = cx.m->cfg.dtype == TM_DTYPE_F16;
+    P.out = f32copy; P.out_nstride = t.nstride;
+    if (launch_prep(P, cx.s) != hipSuccess) { (void)hipFree(dev); (void)hipFree(f32copy); return; }
+    t.p = f32copy;
+  }
   std::vector<float> host(n);
   if (launch_from_cb8(t, dev, cx.s) == hipSuccess && hipStreamSynchronize(cx.s) == hipSuccess &&
       hipMemcpy(host.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -693,6 +721,7 @@ static void dump_tv(Ctx& cx, const std::string& name, const TV& t) {
     if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(host.data(), sizeof(float), n, f); fclose(f); }
   }
   (void)hipFree(dev);
+  if (f32copy) (void)hipFree(f32copy);
 }
 
 static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags,
@@ -720,11 +749,15 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
   }
 }
 
-static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, int cin_real,
-                       const TVH* fuse_a2 = nullptr, const ResW* rw = nullptr, int per_image = 1) {
+// y: geometry of the output; y16: `y.p` is a 16-bit stream tensor (written as such); res16: 16-bit stream residual
+static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res16, int cin_real,
+                       const TVH* fuse_a2 = nullptr, const ResW* rw = nullptr, int per_image = 1, bool y16 = false) {
   if (cx.dry) return;
   ConvLaunchH L;
-  L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res;
+  L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y;
+  TVH resh;
+  if (res16) { resh = as_h(*res16); L.res_h = &resh; }
+  if (y16) { L.y_h = (uint16_t*)y.p; L.yh_nstride = y.nstride; }
   tm_model* m = cx.m;
   if (fuse_a2) {
     L.fuse_norm = 1; L.a2 = *fuse_a2; L.norm_w = rw->n2; L.per_image = per_image;
@@ -745,42 +778,99 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
     m->prof_used++;
     const double vox = (double)x.N * x.Z * x.H * x.W;
     m->prof_nominal += 2.0 * cin_real * cw.Cout * 27.0 * vox;
-    m->prof_bytes += 2.0 * vox * x.Cb * 8 + 2.0 * (double)conv_bf16_pack_elems(cw.Cout, cw.Cbi) + 4.0 * vox * y.Cb * 8;
+    m->prof_bytes += 2.0 * vox * x.Cb * 8 + 2.0 * (double)conv_bf16_pack_elems(cw.Cout, cw.Cbi) +
+                     ((y16 || fuse_a2) ? 2.0 : 4.0) * vox * y.Cb * 8 + (res16 ? 2.0 * vox * y.Cb * 8 : 0.0);
   }
 }
 
 static void run_conv1_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, const TV* gate,
-                        int flags, TVH* y_h = nullptr, const TVH* gate_h = nullptr) {
+                        int flags, TVH* y_h = nullptr, const TVH* gate_h = nullptr, const TVH* res_h = nullptr) {
   if (cx.dry) return;
   ConvLaunchH L;
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
-  L.gate_h = gate_h;
+  L.gate_h = gate_h; L.res_h = res_h;
   if (y_h) { L.y_h = y_h->p; L.yh_nstride = y_h->nstride; }
   cx.check(cx.m->cfg.dtype == TM_DTYPE_F16 ? launch_conv1_f16(L, cx.s) : launch_conv1_bf16(L, cx.s));
+}
+
+// ResBlock._forward (model/MBAblocks.py:237-299) in the 16-bit modes: every tensor that crosses a block boundary (sources,
+// output, the resampled / concatenated x that feeds the skip conv or the residual add) is a 16-bit CB8 stream tensor --
+// as under the reference's fp16 autocast, where every conv output and the residual sum are half tensors
+// (diffusion/base.py:377).  Norm statistics, modulation, SiLU and all accumulation stay fp32.
+static TV res_block_h16(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, int per_image, int S_out, int mode) {
+  tm_model* m = cx.m;
+  const int Z = m->z;
+  const int h_f16 = m->cfg.dtype == TM_DTYPE_F16;
+  TV out = cx.tensor_s(N, w.cout, Z, S_out);
+  const size_t mark = cx.top;
+  const int cbe = (w.cbi + 1) / 2 * 2;
+  TVH Ah = cx.tensor_h(N, cbe, Z, S_out), rawh;
+  const bool need_raw = w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage;
+  if (need_raw) rawh = cx.tensor_h(N, cbe, Z, S_out);
+  if (!cx.dry) {
+    PrepLaunch P;
+    P.nsrc = (int)src.size();
+    for (size_t i = 0; i < src.size(); ++i) {
+      P.src[i].p = src[i].t.p; P.src[i].nstride = src[i].t.nstride; P.src[i].Cb = src[i].t.Cb;
+      P.src[i].collage = src[i].collage ? 1 : 0;
+    }
+    P.src_h = 1; P.h_f16 = h_f16;
+    P.resample = mode; P.N = N; P.Z = Z; P.S = S_out; P.p1 = cx.p1; P.p2 = cx.p2;
+    P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
+    P.out_h = Ah.p; P.out_h_nstride = Ah.nstride; P.pad_blocks = Ah.Cb - w.cbi;
+    if (need_raw) { P.raw_h = rawh.p; P.raw_h_nstride = rawh.nstride; }
+    cx.check(launch_prep(P, cx.s));
+  }
+  // Cout in {64, 128}: one workgroup holds every cout of its voxels, so out_layers' norm -> modulate -> SiLU runs in the
+  // first conv's epilogue and writes the second conv's 16-bit input directly
+  const bool fuse_mid = w.cout == 64 || w.cout == 128;
+  TVH A2h = cx.tensor_h(N, (w.cout / 8 + 1) / 2 * 2, Z, S_out);
+  TV geom; geom.N = N; geom.C = w.cout; geom.Cb = w.cout / 8; geom.Z = Z; geom.H = S_out; geom.W = S_out;
+  geom.nstride = (long)geom.Cb * geom.plane();
+  if (fuse_mid) {
+    run_conv_h(cx, Ah, w.c1h, w.c1, geom, nullptr, w.cin, &A2h, &w, per_image);
+  } else {
+    TV H1 = cx.tensor(N, w.cout, Z, S_out);                  // fp32: the norm statistics are taken on the unrounded conv output
+    run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin);
+    if (!cx.dry) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
+      P.N = N; P.Z = Z; P.S = S_out;
+      P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
+      P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
+      P.mod_stride = m->emb_tot;
+      P.out_h = A2h.p; P.out_h_nstride = A2h.nstride; P.pad_blocks = A2h.Cb - w.cout / 8; P.h_f16 = h_f16;
+      cx.check(launch_prep(P, cx.s));
+    }
+  }
+  TV rawv = geom; rawv.p = (float*)rawh.p; rawv.nstride = rawh.nstride;   // the residual view of rawh (channels < cout only)
+  const TV* r = nullptr;
+  if (w.has_skip) {
+    TVH outh = as_h(out);
+    run_conv1_h(cx, rawh, w.skiph, w.skip, out, nullptr, nullptr, 0, &outh);
+    r = &out;
+  } else if (need_raw) r = &rawv;
+  else r = &src[0].t;
+  run_conv_h(cx, A2h, w.c2h, w.c2, out, r, w.cout, nullptr, nullptr, 1, true);
+  cx.top = mark;
+  return out;
 }
 
 // ResBlock._forward (model/MBAblocks.py:237-299)
 static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, int per_image, int S_out, int mode,
                     TV* out_opt) {
   tm_model* m = cx.m;
+  if (is_h16(m->cfg.dtype)) return res_block_h16(cx, w, src, N, per_image, S_out, mode);
   const int Z = m->z;
   TV out = out_opt ? *out_opt : cx.tensor(N, w.cout, Z, S_out);
   const size_t mark = cx.top;
   int cin_pad = w.cbi * 8;
-  const bool bf16 = is_h16(m->cfg.dtype);
-  const int h_f16 = m->cfg.dtype == TM_DTYPE_F16;
-  TV A, raw, H1, A2;
-  TVH Ah, A2h;
-  if (bf16) Ah = cx.tensor_h(N, (w.cbi + 1) / 2 * 2, Z, S_out);
-  else A = cx.tensor(N, cin_pad, Z, S_out);
+  TV A = cx.tensor(N, cin_pad, Z, S_out), raw, H1, A2;
   // the residual / skip-conv input is the CONCATENATED (and resampled) x, MBAblocks.py:252-258,297:
   // it equals a stored tensor only for a single plain source
   const bool need_raw = w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage;
-  // bf16 mode: a raw that only feeds the skip conv is written as bf16 (no fp32 copy)
-  const bool raw_bf16 = bf16 && w.has_skip;
-  TVH rawh;
-  if (need_raw && raw_bf16) rawh = cx.tensor_h(N, (w.cbi + 1) / 2 * 2, Z, S_out);
-  else if (need_raw) raw = cx.tensor(N, cin_pad, Z, S_out);
+  if (need_raw) raw = cx.tensor(N, cin_pad, Z, S_out);
   if (!cx.dry) {
     PrepLaunch P;
     P.nsrc = (int)src.size();
@@ -790,27 +880,14 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     }
     P.resample = mode; P.N = N; P.Z = Z; P.S = S_out; P.p1 = cx.p1; P.p2 = cx.p2;
     P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
-    if (bf16) { P.out_h = Ah.p; P.out_h_nstride = Ah.nstride; P.pad_blocks = Ah.Cb - w.cbi; P.h_f16 = h_f16; }
-    else { P.out = A.p; P.out_nstride = A.nstride; }
-    if (need_raw && raw_bf16) { P.raw_h = rawh.p; P.raw_h_nstride = rawh.nstride; }
-    else if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
+    P.out = A.p; P.out_nstride = A.nstride;
+    if (need_raw) { P.raw = raw.p; P.raw_nstride = raw.nstride; }
     cx.check(launch_prep(P, cx.s));
   }
-  // bf16, Cout in {64, 128}: one workgroup holds every cout of its voxels, so out_layers' norm -> modulate -> SiLU
-  // runs in the first conv's epilogue and writes the second conv's bf16 input directly
-  const bool fuse_mid = bf16 && (w.cout == 64 || w.cout == 128);
-  if (bf16) A2h = cx.tensor_h(N, (w.cout / 8 + 1) / 2 * 2, Z, S_out);
-  else A2 = cx.tensor(N, w.cout, Z, S_out);
-  if (fuse_mid) {
-    TV geom; geom.N = N; geom.C = w.cout; geom.Cb = w.cout / 8; geom.Z = Z; geom.H = S_out; geom.W = S_out;
-    geom.nstride = (long)geom.Cb * geom.plane();
-    run_conv_h(cx, Ah, w.c1h, w.c1, geom, nullptr, w.cin, &A2h, &w, per_image);
-  } else {
-    H1 = cx.tensor(N, w.cout, Z, S_out);
-    if (bf16) run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin);
-    else run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
-  }
-  if (!cx.dry && !fuse_mid) {
+  A2 = cx.tensor(N, w.cout, Z, S_out);
+  H1 = cx.tensor(N, w.cout, Z, S_out);
+  run_conv(cx, A, w.c1, H1, nullptr, nullptr, 0, w.cin);
+  if (!cx.dry) {
     PrepLaunch P;
     P.nsrc = 1;
     P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
@@ -818,18 +895,8 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
     P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
     P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
     P.mod_stride = m->emb_tot;
-    if (bf16) { P.out_h = A2h.p; P.out_h_nstride = A2h.nstride; P.pad_blocks = A2h.Cb - w.cout / 8; P.h_f16 = h_f16; }
-    else { P.out = A2.p; P.out_nstride = A2.nstride; }
+    P.out = A2.p; P.out_nstride = A2.nstride;
     cx.check(launch_prep(P, cx.s));
-  }
-  if (bf16) {
-    const TV* r = nullptr;
-    if (w.has_skip) { run_conv1_h(cx, rawh, w.skiph, w.skip, out, nullptr, nullptr, 0); r = &out; }
-    else if (need_raw) r = &raw;
-    else r = &src[0].t;
-    run_conv_h(cx, A2h, w.c2h, w.c2, out, r, w.cout);
-    cx.top = mark;
-    return out;
   }
   if (w.has_skip) {
     run_conv(cx, raw, w.skip, out, nullptr, nullptr, 0);
@@ -853,11 +920,13 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     // Activations that only feed a Linear, and the 7C modulation tensor (shift/scale/gate/cross-cond chunks), are
     // produced directly in bf16: the cross-cond chunk is the kv Linear's input as it stands.
     const int gbe = ((w.G + 7) / 8 + 1) / 2 * 2;
+    // src16: the source is a 16-bit stream tensor (x, the RNA level); otherwise an fp32 scratch tensor
     auto prep_h = [&](const float* p, long ns, int Cbs, bool collage, const float* nw, const TVH* sc, const TVH* sh, int act,
-                      TVH dst, int Creal) {
+                      TVH dst, int Creal, bool src16 = true) {
       if (cx.dry) return;
       PrepLaunch P;
       P.nsrc = 1;
+      P.src_h = src16 ? 1 : 0;
       P.src[0].p = p; P.src[0].nstride = ns; P.src[0].Cb = Cbs; P.src[0].collage = collage ? 1 : 0;
       P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = act; P.per_image = per_image;
       P.norm_w = nw; P.inv_c = 1.0f / (float)Creal;
@@ -892,14 +961,16 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
       run_conv1_h(cx, xa, w.qh, w.q, q, nullptr, nullptr, 0);
       run_conv1_h(cx, crs, w.kvh, w.kv, kv, nullptr, nullptr, 0);
       if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, o, cx.s));
-      prep_h(o.p, o.nstride, o.Cb, false, nullptr, nullptr, nullptr, 0, oh, C);
+      prep_h(o.p, o.nstride, o.Cb, false, nullptr, nullptr, nullptr, 0, oh, C, false);
     }
-    run_conv1_h(cx, oh, w.projh, w.proj, x, &x, nullptr, 0, nullptr, &g_a);
+    // x <- x + gate * Linear(.): the 16-bit stream tensor is updated in place (each element is read and written by one lane)
+    TVH xh = as_h(x);
+    run_conv1_h(cx, oh, w.projh, w.proj, x, nullptr, nullptr, 0, &xh, &g_a, &xh);
     prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
     TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);
     TV h1_geom = x; h1_geom.Cb = 4 * cb; h1_geom.C = 4 * C; h1_geom.p = nullptr; h1_geom.nstride = (long)4 * cb * x.plane();
     run_conv1_h(cx, xa, w.fc1h, w.fc1, h1_geom, nullptr, nullptr, EPI_GELU, &h1);
-    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, &x, nullptr, 0, nullptr, &g_m);
+    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, nullptr, nullptr, 0, &xh, &g_m, &xh);
     cx.top = mark;
     return;
   }
@@ -969,6 +1040,13 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
     cx.check(launch_emb_all(te, b, c.embed_ch, m->emb_w, m->emb_b, m->emb_tot, ss, cx.s));
   }
   // ---- RNA pyramid (get_rna, model/unet_ours.py:298-323) ----
+  const bool h16 = is_h16(c.dtype);
+  TV rl16[4];
+  if (h16) {                                                      // 16-bit stream copies of the four levels (persist for the call)
+    int S16 = m->gn * 2;
+    for (int i = 0; i < 4; ++i) { rl16[i] = cx.tensor_s(Ne, m->rw[i], Z, S16); S16 *= 2; }
+  }
+  const size_t rna_mark = cx.top;
   TV tok = cx.tensor(Ne, c.rna_num, c.rna_slc, m->gn);           // gene-attention output, CB8 [Ne][Gb][zs][gn][gn][8]
   if (!cx.dry) {
     cx.check(hipMemsetAsync(tok.p, 0, (size_t)Ne * tok.nstride * sizeof(float), cx.s));      // pad gene slots
@@ -1007,11 +1085,27 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
     run_conv(cx, rs[i - 1], m->pyr[i - 1], rl[i], nullptr, nullptr, EPI_UP2, 0, ZM_INPLANE);   // SiLU -> conv -> Upsample
     S *= 2;
   }
+  if (h16) {
+    // the RNA path itself stays fp32 (0.2 % of the FLOPs); its four levels enter the 16-bit activation stream here
+    for (int i = 0; i < 4; ++i) {
+      if (!cx.dry) {
+        PrepLaunch P;
+        P.nsrc = 1;
+        P.src[0].p = rl[i].p; P.src[0].nstride = rl[i].nstride; P.src[0].Cb = rl[i].Cb;
+        P.N = Ne; P.Z = Z; P.S = rl[i].H; P.h_f16 = c.dtype == TM_DTYPE_F16;
+        P.out_h = (uint16_t*)rl16[i].p; P.out_h_nstride = rl16[i].nstride;
+        cx.check(launch_prep(P, cx.s));
+      }
+      rl[i] = rl16[i];
+    }
+    cx.top = rna_mark;                                            // the fp32 levels and their scratch are dead
+  }
   for (int i = 0; i < 4; ++i) { TV v = rl[i]; v.C = m->rw[i]; dump_tv(cx, "rna." + std::to_string(i), v); }
   // ---- stem ----
   std::vector<std::vector<TV>> skips(L);
-  TV h = cx.tensor(Ne, c.net_ch, Z, ps);
-  if (!cx.dry) cx.check(launch_stem(x, h, m->stem.w, m->stem.bias, c.n_stain, cx.s));
+  TV h = cx.tensor_s(Ne, c.net_ch, Z, ps);
+  if (!cx.dry) cx.check(launch_stem(x, h, m->stem.w, m->stem.bias, c.n_stain, cx.s, h16 ? (uint16_t*)h.p : nullptr, h.nstride,
+                                    c.dtype == TM_DTYPE_F16));
   skips[0].push_back(h);
   dump_tv(cx, "stem", h);
   // ---- encoder ----
@@ -1066,6 +1160,7 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
       PrepLaunch P;
       P.nsrc = 1;
       P.src[0].p = hd.p; P.src[0].nstride = hd.nstride; P.src[0].Cb = hd.Cb;
+      P.src_h = h16 ? 1 : 0; P.h_f16 = c.dtype == TM_DTYPE_F16;
       P.N = N; P.Z = Z; P.S = ps; P.norm_w = m->out_norm; P.inv_c = 1.0f / (float)c.net_ch; P.act = 1; P.per_image = per;
       P.out = A.p; P.out_nstride = A.nstride;
       cx.check(launch_prep(P, cx.s));
@@ -1214,7 +1309,7 @@ extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void
 // shared body of the 16-bit 3x3x3 conv test entry points: fp32 CB8 input -> 16-bit CB8 (prep kernel), then the conv
 static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin, int Cout,
                          int S, int dtype, int waves, const void* norm_w_host, const void* scale_host, const void* shift_host,
-                         int per_image, void* a2_out, void* stream) {
+                         int per_image, void* a2_out, void* stream, const void* res_h16 = nullptr, void* y_h16 = nullptr) {
   if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
   if (waves != 0 && waves != 4 && waves != 8) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4 or 8");
   const bool f16 = dtype == TM_DTYPE_F16, fused = norm_w_host != nullptr;
@@ -1252,6 +1347,9 @@ static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias
   L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = 2; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
   L.w = dw; L.bias = df; L.Cout = Cout; L.force_waves = waves;
   L.y = view_cb8(y_cb8, N, Cout, 2, S, S);
+  TVH resh = as_h(L.y);
+  if (res_h16) { resh.p = (uint16_t*)const_cast<void*>(res_h16); L.res_h = &resh; }
+  if (y_h16) { L.y_h = (uint16_t*)y_h16; L.yh_nstride = L.y.nstride; }
   if (fused) {
     L.fuse_norm = 1; L.norm_w = df + nt64 * 64; L.mod_scale = L.norm_w + Cout; L.mod_shift = L.mod_scale + (size_t)nimg * Cout;
     L.mod_stride = Cout; L.per_image = per_image;
@@ -1267,9 +1365,10 @@ static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias
   return TM_OK;
 }
 extern "C" int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
-                                 int Cout, int S, int dtype, int waves, void* stream) {
-  if (!x_cb8 || !w_host || !bias_host || !y_cb8) return fail(TM_ERR_ARG, "null argument");
-  return op_conv27_h16(x_cb8, w_host, bias_host, y_cb8, N, Cin, Cout, S, dtype, waves, nullptr, nullptr, nullptr, 1, nullptr, stream);
+                                 int Cout, int S, int dtype, int waves, const void* res_h16, void* y_h16, void* stream) {
+  if (!x_cb8 || !w_host || !bias_host || (!y_cb8 && !y_h16)) return fail(TM_ERR_ARG, "null argument");
+  return op_conv27_h16(x_cb8, w_host, bias_host, y_cb8 ? y_cb8 : y_h16, N, Cin, Cout, S, dtype, waves, nullptr, nullptr, nullptr, 1,
+                       nullptr, stream, res_h16, y_h16);
 }
 extern "C" int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const void* bias_host, const void* norm_w_host,
                                   const void* scale_host, const void* shift_host, void* a2_out, int N, int Cin, int Cout,
@@ -1280,7 +1379,10 @@ extern "C" int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const v
                        per_image, a2_out, stream);
 }
 extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
-                                int Cout, int Z, int S, int gelu, int dtype, int waves, void* stream) {
+                                int Cout, int Z, int S, int gelu, int dtype, int waves, const void* res_h16, const void* gate_h16,
+                                void* y_h16, void* stream) {
+  if (!x_cb8 || !w_host || !bias_host || (!y_cb8 && !y_h16)) return fail(TM_ERR_ARG, "null argument");
+  if (!y_cb8) y_cb8 = y_h16;                              // geometry carrier only
   if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
   if (waves != 0 && waves != 4 && waves != 8) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4 or 8");
   const bool f16 = dtype == TM_DTYPE_F16;
@@ -1309,6 +1411,10 @@ extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const voi
   L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = Z; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
   L.w = dw; L.bias = db; L.Cout = Cout; L.flags = gelu ? EPI_GELU : 0; L.force_waves = waves;
   L.y = view_cb8(y_cb8, N, Cout, Z, S, S);
+  TVH resh = as_h(L.y), gateh = as_h(L.y);
+  if (res_h16) { resh.p = (uint16_t*)const_cast<void*>(res_h16); L.res_h = &resh; }
+  if (gate_h16) { gateh.p = (uint16_t*)const_cast<void*>(gate_h16); L.gate_h = &gateh; }
+  if (y_h16) { L.y_h = (uint16_t*)y_h16; L.yh_nstride = L.y.nstride; }
   hipError_t e = (f16 ? launch_conv1_f16 : launch_conv1_bf16)(L, st);
   hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dx);

@@ -135,6 +135,39 @@ def test_conv27_bf16_exact_integers(N, Cin, Cout, S, waves, dtype):
         assert float(raw[:, -1, ..., Cout % 8:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Cin,Cout,S", [(5, 24, 64, 8), (3, 40, 192, 16), (2, 16, 128, 32), (1, 24, 128, 64), (9, 229, 512, 8)])
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv27_16bit_stream_epilogue(N, Cin, Cout, S, waves, dtype):
+    """The model's form of the second ResBlock conv in the 16-bit modes: 16-bit CB8 residual in, 16-bit CB8 result out
+    (16-byte accesses after a v_permlane32_swap of the accumulator quads).  Integer operands: the fp32 value
+    conv + bias + res is exact, so the only rounding is the final RNE to the 16-bit type -- bit-exact against torch."""
+    td = util.H16[dtype][1]
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 71)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 72)
+    b = util.rand_int((Cout,), -4, 4, 73)
+    res = util.rand_int((N, Cout, 2, S, S), -100, 100, 74)
+    ref = (F.conv3d(x, w, b, padding=1) + res).to(td).float()
+    got, raw = util.conv27_bf16(x.to(DEV), w, b, dtype, waves, res=res.to(DEV), out16=True)
+    assert torch.equal(got.cpu(), ref), util.report("conv27 stream " + dtype, got, ref)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Z,S", [(2, 229, 1792, 2, 8), (3, 13, 40, 2, 8), (1, 96, 64, 2, 64), (7, 128, 64, 2, 16)])
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv1_16bit_stream_epilogue(N, Cin, Cout, Z, S, waves, dtype):
+    """x <- x + gate * Linear(.) with 16-bit gate, residual and output (AttnBlock, model/MBAblocks.py:486-489)."""
+    td = util.H16[dtype][1]
+    x = util.rand_int((N, Cin, Z, S, S), -3, 3, 81)
+    w = util.rand_int((Cout, Cin, 1, 1, 1), -2, 2, 82)
+    b = util.rand_int((Cout,), -4, 4, 83)
+    res = util.rand_int((N, Cout, Z, S, S), -100, 100, 84)
+    gate = util.rand_int((N, Cout, Z, S, S), -2, 2, 85)
+    ref = (res + gate * F.conv3d(x, w, b)).to(td).float()
+    got, _ = util.conv1_bf16(x.to(DEV), w, b, False, dtype, waves, res=res.to(DEV), gate=gate.to(DEV), out16=True)
+    assert torch.equal(got.cpu(), ref), util.report("conv1 stream " + dtype, got, ref)
+
+
 def test_conv27_bf16_random_vs_bf16_rounded_reference():
     g = torch.Generator().manual_seed(17)
     N, Cin, Cout, S = 2, 741, 512, 8

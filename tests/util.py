@@ -62,16 +62,27 @@ def conv_mfma(x, w, b, ksize, variant=0, zmode=0, up2=False):
 H16 = {"bf16": (1, torch.bfloat16), "f16": (2, torch.float16)}
 
 
-def conv27_bf16(x, w, b, dtype="bf16", waves=0):
+def to_cb8_h16(x, dtype):
+    """NCDHW fp32 cuda -> 16-bit CB8 cuda tensor [N][ceil(C/8)][Z][H][W][8]."""
+    return to_cb8(x).to(H16[dtype][1])
+
+
+def conv27_bf16(x, w, b, dtype="bf16", waves=0, res=None, out16=False):
     """x NCDHW cuda (Z == 2); rounds x (device) and w (host) to the 16-bit `dtype`, fp32 accumulate.
-    waves: 0 = the launcher's choice, 4 / 8 = force that workgroup form."""
+    waves: 0 = the launcher's choice, 4 / 8 = force that workgroup form.  res: NCDHW residual handed over as a 16-bit CB8
+    tensor; out16: take the result as a 16-bit CB8 tensor (the model's activation-stream form).  Returns fp32 NCDHW."""
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
     xc = to_cb8(x)
-    yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
+    shp = (N, (Cout + 7) // 8, Z, S, S, 8)
+    yc = torch.zeros(shp, dtype=torch.float32, device=x.device) if not out16 else None
+    yh = torch.zeros(shp, dtype=H16[dtype][1], device=x.device) if out16 else None
+    rh = to_cb8_h16(res, dtype) if res is not None else None
     wh, bh = w.contiguous().float(), b.contiguous().float()
     _lib.check(_lib.lib().tm_op_conv27_bf16(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
-                                            N, Cin, Cout, S, H16[dtype][0], waves, _lib.current_stream_ptr()), "tm_op_conv27_bf16")
+                                            N, Cin, Cout, S, H16[dtype][0], waves, _lib.ptr(rh), _lib.ptr(yh),
+                                            _lib.current_stream_ptr()), "tm_op_conv27_bf16")
+    yc = yh.float() if out16 else yc
     return from_cb8(yc, Cout), yc
 
 
@@ -89,15 +100,20 @@ def conv27_fused(x, w, b, norm_w, scale, shift, per_image, dtype="bf16", waves=0
     return from_cb8(a2.float(), Cout)
 
 
-def conv1_bf16(x, w, b, gelu=False, dtype="bf16", waves=0):
+def conv1_bf16(x, w, b, gelu=False, dtype="bf16", waves=0, res=None, gate=None, out16=False):
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
     xc = to_cb8(x)
-    yc = torch.zeros((N, (Cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=x.device)
+    shp = (N, (Cout + 7) // 8, Z, S, S, 8)
+    yc = torch.zeros(shp, dtype=torch.float32, device=x.device) if not out16 else None
+    yh = torch.zeros(shp, dtype=H16[dtype][1], device=x.device) if out16 else None
+    rh = to_cb8_h16(res, dtype) if res is not None else None
+    gh = to_cb8_h16(gate, dtype) if gate is not None else None
     wh, bh = w.contiguous().float(), b.contiguous().float()
     _lib.check(_lib.lib().tm_op_conv1_bf16(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
-                                           N, Cin, Cout, Z, S, int(gelu), H16[dtype][0], waves, _lib.current_stream_ptr()),
-               "tm_op_conv1_bf16")
+                                           N, Cin, Cout, Z, S, int(gelu), H16[dtype][0], waves, _lib.ptr(rh), _lib.ptr(gh),
+                                           _lib.ptr(yh), _lib.current_stream_ptr()), "tm_op_conv1_bf16")
+    yc = yh.float() if out16 else yc
     return from_cb8(yc, Cout), yc
 
 
