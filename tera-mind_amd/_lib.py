@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libteramind_hip.so")
+# TM_LIB_PATH: diagnostic builds only (csrc `make diag`: the same library with in-kernel time stamps, tools/conv27_stamps.py)
+LIB_PATH = os.environ.get("TM_LIB_PATH") or os.path.join(_HERE, "csrc", "libteramind_hip.so")
 
 c_void_p, c_int, c_size_t, c_char_p, c_float = C.c_void_p, C.c_int, C.c_size_t, C.c_char_p, C.c_float
 c_i64_p = C.POINTER(C.c_int64)

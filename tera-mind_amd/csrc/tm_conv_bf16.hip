@@ -148,6 +148,7 @@ __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 
 // quad of block 2q + 1 away and receives the partner's quad of block 2q), so that a 16-bit CB8 entry (8 couts = 16 bytes)
 // is read (gate, residual) and written by ONE lane: half the memory instructions of the 8-byte-per-lane form, each at the
 // full 16-byte width.  Arithmetic and its order are those of conv_epilogue: (acc + bias) -> GELU -> * gate -> res + .
+template <bool GATE>
 __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&acc)[2][4], int cob0, int h,
                                                   const int (&on)[4], const int (&ooff)[4]) {
   typedef h16_t h16x8 __attribute__((ext_vector_type(8)));
@@ -156,9 +157,23 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int cob = cob0 + ct * 4 + 2 * q + h;            // the block this lane owns after the swap
-      const bool cob_ok = cob < a.Cob;
+      // (1) the 16-bit gate / residual entries of this quarter of the wave tile are requested up front with UNCONDITIONAL
+      //     loads (lanes without a valid voxel / cout block read element 0 of the tensor): four (eight with a gate)
+      //     independent 16-byte loads in flight instead of load -> use -> store chains behind per-voxel branches
+      h16x8 rb[4], gb[4];
+      bool ok[4];
+      long pl[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        ok[mt] = cob < a.Cob && ooff[mt] >= 0;
+        pl[mt] = ok[mt] ? (long)cob * a.y_plane + ooff[mt] : 0;
+        if (a.res_h) rb[mt] = *(const h16x8*)(a.res_h + (ok[mt] ? (long)on[mt] * a.res_h_nstride : 0) + pl[mt]);
+        if (GATE && a.gate_h) gb[mt] = *(const h16x8*)(a.gate_h + (ok[mt] ? (long)on[mt] * a.gate_h_nstride : 0) + pl[mt]);
+      }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-      if (cob_ok) { b0 = *(const f32x4*)(a.bias + (long)cob * 8); b1 = *(const f32x4*)(a.bias + (long)cob * 8 + 4); }
+      if (cob < a.Cob) { b0 = *(const f32x4*)(a.bias + (long)cob * 8); b1 = *(const f32x4*)(a.bias + (long)cob * 8 + 4); }
+      __builtin_amdgcn_sched_barrier(0);
+      // (2) swap, bias, GELU, gate, residual, round, store
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         float o[8];
@@ -170,39 +185,40 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
           o[j] = __uint_as_float(r[0]) + b0[j];
           o[4 + j] = __uint_as_float(r[1]) + b1[j];
         }
-        if (!cob_ok || ooff[mt] < 0) continue;
         if (a.flags & EPI_GELU) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = gelu_tanh_f(o[j]);
         }
-        const long pl = (long)cob * a.y_plane + ooff[mt];
-        if (a.gate_h) {
-          const h16x8 gb = *(const h16x8*)(a.gate_h + (long)on[mt] * a.gate_h_nstride + pl);
+        if (GATE && a.gate_h) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] *= (float)gb[j];
-        } else if (a.gate) {
-          const float* gp = a.gate + (long)on[mt] * a.gate_nstride + pl;
-          const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+          for (int j = 0; j < 8; ++j) o[j] *= (float)gb[mt][j];
+        } else if (GATE && a.gate) {
+          if (ok[mt]) {
+            const float* gp = a.gate + (long)on[mt] * a.gate_nstride + pl[mt];
+            const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { o[j] *= g0[j]; o[4 + j] *= g1[j]; }
+            for (int j = 0; j < 4; ++j) { o[j] *= g0[j]; o[4 + j] *= g1[j]; }
+          }
         }
         if (a.res_h) {
-          const h16x8 rb = *(const h16x8*)(a.res_h + (long)on[mt] * a.res_h_nstride + pl);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (float)rb[j] + o[j];
+          for (int j = 0; j < 8; ++j) o[j] = (float)rb[mt][j] + o[j];
         } else if (a.res) {
-          const float* rp = a.res + (long)on[mt] * a.res_nstride + pl;
-          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+          if (ok[mt]) {
+            const float* rp = a.res + (long)on[mt] * a.res_nstride + pl[mt];
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { o[j] = r0[j] + o[j]; o[4 + j] = r1[j] + o[4 + j]; }
+            for (int j = 0; j < 4; ++j) { o[j] = r0[j] + o[j]; o[4 + j] = r1[j] + o[4 + j]; }
+          }
         }
+        if (!ok[mt]) continue;
         if (a.y_h) {
           h16x8 ob;
 #pragma unroll
           for (int j = 0; j < 8; ++j) ob[j] = (h16_t)o[j];
-          *(h16x8*)(a.y_h + (long)on[mt] * a.yh_nstride + pl) = ob;
+          *(h16x8*)(a.y_h + (long)on[mt] * a.yh_nstride + pl[mt]) = ob;
         } else {
-          float* yp = a.y + (long)on[mt] * a.y_nstride + pl;
+          float* yp = a.y + (long)on[mt] * a.y_nstride + pl[mt];
           *(f32x4*)yp = f32x4{o[0], o[1], o[2], o[3]};
           *(f32x4*)(yp + 4) = f32x4{o[4], o[5], o[6], o[7]};
         }
@@ -255,12 +271,36 @@ __device__ __forceinline__ void col_to_vox(int T, int i32, int& ps, int& r, int&
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+#ifdef TM_STAMPS
+// Diagnostic build only (make diag -> libteramind_hip_diag.so, tools/conv27_stamps.py): wave 0 of every workgroup records
+// s_memtime at kernel entry, main-loop entry, main-loop exit and kernel exit into a buffer of its own.
+__device__ unsigned long long* g_tm_stamps = nullptr;      // [capacity][8]: t0 t1 t2 t3 grid bid tag realtime
+__device__ unsigned int g_tm_stamp_cap = 0;
+__device__ unsigned int g_tm_stamp_next = 0;
+#define TM_STAMP(i) do { if (stamp_slot) stamp_slot[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TM_STAMP(i) do { } while (0)
+#endif
+
 template <int TN, int TW, bool FUSE, int NWV = 8>
 __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   using G = HGeo<TN, TW, NWV>;
   constexpr int NT = G::NT;
   const ConvArgs& a = ah.c;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+#ifdef TM_STAMPS
+  unsigned long long* stamp_slot = nullptr;
+  if (threadIdx.x == 0 && g_tm_stamps) {
+    const unsigned int k = atomicAdd(&g_tm_stamp_next, 1u);
+    if (k < g_tm_stamp_cap) {
+      stamp_slot = g_tm_stamps + (size_t)k * 8;
+      stamp_slot[4] = gridDim.x; stamp_slot[5] = blockIdx.x;
+      stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + (unsigned long long)(TN * 1000 + TW * 10 + (FUSE ? 1 : 0));
+      stamp_slot[7] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  TM_STAMP(0);
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -342,24 +382,34 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   // z_size 1, 2 or 3 for z_size 4 / 8 -- planes in the zero padding are never staged nor multiplied
   const int zi0 = zo > 0 ? zo - 1 : 0;
   const int npl = (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;
-  auto issue_stage = [&](int hs) {
+  // LDS-DMA piece p (0 .. PW + PX - 1) of stage hs: the weight pieces first, then the halo-tile pieces
+  auto issue_piece = [&](int hs, int p) {
     const int cbp = hs / npl, zi = zi0 + hs % npl;
     u32x4* base = lds16 + (hs & 1) * G::BUF16;
-    const h16_t* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
-#pragma unroll
-    for (int k = 0; k < G::PW; ++k)
+    if (p < G::PW) {
+      const int k = p;
+      const h16_t* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
       if (G::WPIECES % NT == 0 || k * NT + wv * 64 < G::WPIECES) TM_GLDS16(wp + (long)k * NT * 8, base + k * NT + wv * 64);
-    const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
-#pragma unroll
-    for (int k = 0; k < G::PX; ++k)
+    } else {
+      const int k = p - G::PW;
+      const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
       if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * NT + wv * 64);
+    }
   };
+  constexpr int NP = G::PW + G::PX;                    // DMA instructions per wave per stage
+  // The next stage's DMAs are not issued in one burst behind the barrier (every wave of the workgroup would then spend the
+  // same ~100 cycles per instruction issuing them while all four matrix pipes idle) but PPT at a time behind the MFMA
+  // groups of taps 0 .. 3: a wave's VMEM issue overlaps its own and its SIMD partner's MFMAs, and the last piece still
+  // has five taps (~2.5k cycles) to land before the barrier.
+  constexpr int PPT = (NP + 3) / 4;
 
   const int NH = npl * ah.Cbp;
-  issue_stage(0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) issue_piece(0, p);
   __syncthreads();
+  TM_STAMP(1);
   for (int hs = 0; hs < NH; ++hs) {
-    if (hs + 1 < NH) issue_stage(hs + 1);
+    const bool more = hs + 1 < NH;
     const u32x4* buf = lds16 + (hs & 1) * G::BUF16;
     // fragment registers are double-buffered by hand: tap t+1's ds_reads are issued before tap t's MFMAs
     bf16x8 wf[2][2], xf[2][4];
@@ -370,6 +420,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int cur = tap & 1, nxt = cur ^ 1;
+      // This tap's fragments were requested one tap ago, behind eight MFMAs: they have long landed.  Saying so HERE, before
+      // the next tap's reads are issued, keeps hipcc from waiting lgkmcnt(0) after them (it does not emit a counted
+      // lgkmcnt(6) in this loop), which would expose a full LDS round trip in front of every second MFMA group.
+      if (tap > 0) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0) only (vmcnt / expcnt fields = no wait)
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (tap < 8) {
         const int t1 = tap + 1;
         const int xd = (t1 / 3) * G::HCP + (t1 % 3);
@@ -387,12 +444,38 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
         for (int mt = 0; mt < 4; ++mt)
           acc[ct][mt] = TM_MFMA16(wf[cur][ct], xf[cur][mt], acc[ct][mt]);
       __builtin_amdgcn_sched_barrier(0);
+      if (more && tap < 4) {
+#pragma unroll
+        for (int p = tap * PPT; p < (tap + 1) * PPT && p < NP; ++p) issue_piece(hs + 1, p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();          // drains this wave's LDS-DMA (vmcnt) and fences the buffer swap
   }
+  TM_STAMP(2);
   if (FUSE) fused_norm_epilogue<G::WNW>(ah, acc, wn, wm, i32, h, on, ooff, (float*)lds16);
-  else conv_epilogue_h16(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
+  else conv_epilogue_h16<false>(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
+#ifdef TM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TM_STAMP(3);
+#endif
 }
+#ifdef TM_STAMPS
+#ifndef TM_H16_F16
+extern "C" int tm_diag_stamps(unsigned long long* dev_buf, unsigned int capacity) {     // dev_buf == null: disable
+  unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tm_stamps), &dev_buf, sizeof(dev_buf)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tm_stamp_cap), &capacity, sizeof(capacity)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tm_stamp_next), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+extern "C" int tm_diag_stamp_count(void) {
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tm_stamp_next), sizeof(n)) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif
+#endif
 
 // ---- 1x1x1 conv / Linear on '(z h w) c' tokens, bf16 operands (flat voxel tiles) -----------
 // No tap reuse: at the matrix-pipe rate the staging traffic is 4096*(1/TN + 1/TM) = 40 B/clk/CU, i.e. about
@@ -527,7 +610,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail's dummy DMAs before the LDS is released
-  conv_epilogue_h16(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
+  conv_epilogue_h16<true>(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
 }
 
 
