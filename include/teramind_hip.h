@@ -222,6 +222,16 @@ int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_hos
                      int N, int Cin, int Cout, int Z, int S, int gelu, int dtype, int waves, const void* res_h16,
                      const void* gate_h16, void* y_h16, void* stream);
 
+/* The ResBlock skip conv as the 16-bit modes run it (model/MBAblocks.py:220-224,297 on x = th.cat((h, skip, rna), 1),
+ * model/unet_ours.py:384,418, with to_collage :325-341 applied to the sources of the collage decoder): a 1x1x1 conv whose
+ * input is the channel concat of nsrc (1..3) tensors READ IN PLACE -- the concat and the half-patch re-tiling are address
+ * rules of the kernel's staging, not tensors.  x_cb8[i]: fp32 CB8 [Ni, cin[i], Z, S, S] (device), Ni = N for a plain
+ * source, N / ((p1-1)(p2-1)) * p1 * p2 for a collaged one (collage[i] != 0: the source lives on the (p1 x p2) encoder
+ * patch grid of each image and is read at the half-patch-shifted position).  w [Cout][sum cin] HOST.  Output fp32 CB8. */
+int tm_op_conv1_concat(const void* const* x_cb8, const int* cin, const int* collage, int nsrc, const void* w_host,
+                       const void* bias_host, void* y_cb8, int N, int Cout, int Z, int S, int p1, int p2,
+                       int dtype, int waves, void* stream);
+
 /* Windowed gene-patch cross attention core (model/MBAblocks.py:551-601 between the q/k/v Linears and proj):
  * q, k, v fp32 CB8 [N, C, Z, S, S]; qw, kw: device fp32 [C] (q_norm / k_norm weights).
  * dtype TM_DTYPE_F32: fp32 MFMA kernels, out = fp32 CB8.  TM_DTYPE_BF16: inputs are rounded to bf16 first (what the

@@ -62,6 +62,15 @@ struct ConvArgsH {
   long mod_stride; int per_image; float inv_c;
   uint16_t* a2; long a2_nstride;
 };
+// conv1 only: the input as a channel concat of up to three 16-bit CB8 tensors, read in place (the ResBlock skip conv:
+// th.cat((h, skip, rna), 1) and to_collage are address rules of the x staging, never materialised).  Virtual channel
+// block vb of the concat lives in source s = [vb >= cb1] + [vb >= cb2] at block vb - cb_s; a collaged source is read at
+// the half-patch-shifted position of the (p1 x p2) source patch grid (model/unet_ours.py:325-341).
+struct ConcatX {
+  int nsrc;                       // 0: single tensor `c.x` (x_nstride_e)
+  const uint16_t *p0, *p1p, *p2p; long ns0, ns1, ns2; int cb1, cb2; int col0, col1, col2;
+  int cbtot, p1, p2;
+};
 
 template <int WNW>
 __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 (&acc)[2][4], int wn, int wm, int i32, int h,
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   const int zi0 = zo > 0 ? zo - 1 : 0;
   const int npl = (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;
   // LDS-DMA piece p (0 .. PW + PX - 1) of stage hs: the weight pieces first, then the halo-tile pieces
-  auto issue_piece = [&](int hs, int p) {
+  auto issue_piece = [&](int hs, int p) __attribute__((always_inline)) {
     const int cbp = hs / npl, zi = zi0 + hs % npl;
     u32x4* base = lds16 + (hs & 1) * G::BUF16;
     if (p < G::PW) {
@@ -501,8 +510,8 @@ struct H1Geo {
   static constexpr int LDS_BYTES = NB * BUF16 * 16;
 };
 
-template <int TN, int NWV>
-__global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const void* zero_page) {
+template <int TN, int NWV, bool MS>        // MS: multi-source (concat / collage) input
+__global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const void* zero_page, ConcatX cx) {
   using G = H1Geo<TN, NWV>;
   constexpr int NT = G::NT;
   static_assert(G::WPIECES <= G::WSLOTS && G::XPIECES % NT == 0 && G::WSLOTS % NT == 0, "staging shape");
@@ -520,19 +529,46 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   const h16_t* wg = (const h16_t*)a.w;
   const h16_t* zp = (const h16_t*)zero_page;
 
+  // piece i = tid + k*NT -> LDS slot WSLOTS + i ([kp][k-half][voxel]); (kp, half) are the same for every lane of an
+  // instruction (NT divides TM or equals it), the voxel differs per lane.  Per piece: the voxel's element offset inside
+  // a channel-block plane and its patch index, as they stand and (multi-source input) after the collage remap.
   long xoff[G::PX];
-  int xkp[G::PX];
+  int xkp[G::PX], xhalf[G::PX];
+  int xn[G::PX], xo[G::PX], xnc[G::PX], xoc[G::PX];     // multi-source only
+  constexpr bool multi = MS;
+  const h16_t *ms_p0 = (const h16_t*)cx.p0, *ms_p1 = (const h16_t*)cx.p1p, *ms_p2 = (const h16_t*)cx.p2p;
+  const long ms_ns0 = cx.ns0, ms_ns1 = cx.ns1, ms_ns2 = cx.ns2;
+  const int ms_cb1 = cx.cb1, ms_cb2 = cx.cb2, ms_cbtot = cx.cbtot;
+  const bool ms_col0 = cx.col0 != 0, ms_col1 = cx.col1 != 0, ms_col2 = cx.col2 != 0;
+  const int ms_S = a.S, ms_q1 = cx.p1 - 1, ms_q2 = cx.p2 - 1, ms_pp1 = cx.p1, ms_pp2 = cx.p2;
+  const long ms_plane = ah.x_plane_e;
 #pragma unroll
   for (int k = 0; k < G::PX; ++k) {
-    const int i = tid + k * NT;                        // piece i -> LDS slot WSLOTS + i  ([kp][k-half][voxel])
+    const int i = tid + k * NT;
     const int v = i % G::TM;
     const int half = (i / G::TM) & 1;
     xkp[k] = i / (2 * G::TM);
+    xhalf[k] = half;
     const long vg = (long)mtile * G::TM + v;
     long off = -1;
+    xn[k] = -1; xo[k] = 0; xnc[k] = 0; xoc[k] = 0;
     if (vg < vtot) {
       const long n = vg / VPN;
-      off = n * ah.x_nstride_e + (long)half * ah.x_plane_e + (vg - n * VPN) * 8;
+      const int rem = (int)(vg - n * VPN);
+      off = n * ah.x_nstride_e + (long)half * ah.x_plane_e + (long)rem * 8;
+      if (multi) {
+        const int S = ms_S;
+        const int z = rem / (S * S), r2 = rem - z * S * S;
+        const int y = r2 / S, x = r2 - y * S;
+        const int q1 = ms_q1, q2 = ms_q2;
+        const int bi = (int)n / (q1 * q2), q = (int)n - bi * q1 * q2;
+        int pi = q / q2, pj = q - pi * q2;
+        int ys = y + S / 2, xs = x + S / 2;
+        if (ys >= S) { ys -= S; pi += 1; }
+        if (xs >= S) { xs -= S; pj += 1; }
+        xn[k] = (int)n; xo[k] = rem * 8;
+        xnc[k] = bi * ms_pp1 * ms_pp2 + pi * ms_pp2 + pj; xoc[k] = ((z * S + ys) * S + xs) * 8;
+      }
     }
     xoff[k] = off;
   }
@@ -562,38 +598,56 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
       for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
 
   const int NS = (ah.Cbp + G::KP - 1) / G::KP;
-  auto issue_stage = [&](int st) {                      // exactly LPS LDS-DMA instructions, whatever st is
-    const int p0 = st * G::KP;
-    u32x4* base = lds16 + (st % G::NB) * G::BUF16;
-    // the source address is selected arithmetically and laundered through a VGPR: a `cond ? ptr : zp` that
-    // hipcc turns into two predicated DMA instructions would break the per-stage instruction count
-#pragma unroll
-    for (int k = 0; k < G::PW; ++k) {
-      const int i = tid + k * NT;
-      const bool wok = st < NS && i < G::WPIECES && p0 + i / (TN * 2) < ah.Cbp;
-      unsigned long long wa = wok ? (unsigned long long)(wsrc + (long)p0 * TN * 16 + (long)k * NT * 8) : (unsigned long long)zp;
-      asm volatile("" : "+v"(wa));
-      TM_GLDS16((const void*)wa, base + k * NT + wv * 64);
+  // One loop over it = -(NB-1) .. NS-1: iteration `it` first issues stage it + NB - 1 (exactly LPS LDS-DMA instructions,
+  // whatever the stage is: the ring fill, the steady state and the dummy tail are the same code, at ONE site -- a
+  // capturing lambda used from two places kept every captured local, the kernel arguments included, in scratch) and then,
+  // for it >= 0, computes stage `it`.
+  for (int it = -(G::NB - 1); it < NS; ++it) {
+    if (it >= 0) {
+      // stage `it` has landed once at most (NB-2) younger stages of this wave are still in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NB - 2) * G::LPS) : "memory");
+      __builtin_amdgcn_s_barrier();                     // everyone's share landed; buffer (it-1)%NB is free
+      __builtin_amdgcn_sched_barrier(0);
     }
+    {
+      const int st = it + G::NB - 1;
+      const int p0 = st * G::KP;
+      u32x4* base = lds16 + (st % G::NB) * G::BUF16;
+      // the source address is selected arithmetically and laundered through a VGPR: a `cond ? ptr : zp` that
+      // hipcc turns into two predicated DMA instructions would break the per-stage instruction count
 #pragma unroll
-    for (int k = 0; k < G::PX; ++k) {
-      const int pr = p0 + xkp[k];
-      const bool ok = st < NS && xoff[k] >= 0 && pr < ah.Cbp;
-      unsigned long long xa = ok ? (unsigned long long)(xg + (long)pr * 2 * ah.x_plane_e + xoff[k]) : (unsigned long long)zp;
-      asm volatile("" : "+v"(xa));
-      TM_GLDS16((const void*)xa, base + G::WSLOTS + k * NT + wv * 64);
+      for (int k = 0; k < G::PW; ++k) {
+        const int i = tid + k * NT;
+        const bool wok = st < NS && i < G::WPIECES && p0 + i / (TN * 2) < ah.Cbp;
+        unsigned long long wa = wok ? (unsigned long long)(wsrc + (long)p0 * TN * 16 + (long)k * NT * 8) : (unsigned long long)zp;
+        asm volatile("" : "+v"(wa));
+        TM_GLDS16((const void*)wa, base + k * NT + wv * 64);
+      }
+#pragma unroll
+      for (int k = 0; k < G::PX; ++k) {
+        const int pr = p0 + xkp[k];
+        unsigned long long xa;
+        if (multi) {
+          const int vb = 2 * pr + xhalf[k];              // virtual channel block of the concat (wave-uniform)
+          // source select by scalar compares (no dynamically indexed kernel-argument loads inside the K loop)
+          const bool g1 = vb >= ms_cb1, g2 = vb >= ms_cb2;
+          const h16_t* sp = g2 ? ms_p2 : (g1 ? ms_p1 : ms_p0);
+          const long sns = g2 ? ms_ns2 : (g1 ? ms_ns1 : ms_ns0);
+          const int scb = g2 ? ms_cb2 : (g1 ? ms_cb1 : 0);
+          const bool col = g2 ? ms_col2 : (g1 ? ms_col1 : ms_col0);
+          const bool ok = st < NS && xn[k] >= 0 && vb < ms_cbtot;
+          const long o = (long)(col ? xnc[k] : xn[k]) * sns + (col ? xoc[k] : xo[k]) + (long)(vb - scb) * ms_plane;
+          xa = ok ? (unsigned long long)(sp + o) : (unsigned long long)zp;
+        } else {
+          const bool ok = st < NS && xoff[k] >= 0 && pr < ah.Cbp;
+          xa = ok ? (unsigned long long)(xg + (long)pr * 2 * ah.x_plane_e + xoff[k]) : (unsigned long long)zp;
+        }
+        asm volatile("" : "+v"(xa));
+        TM_GLDS16((const void*)xa, base + G::WSLOTS + k * NT + wv * 64);
+      }
     }
-  };
-
-#pragma unroll
-  for (int st = 0; st < G::NB - 1; ++st) issue_stage(st);
-  for (int st = 0; st < NS; ++st) {
-    // stage st has landed once at most (NB-2) younger stages of this wave are still in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NB - 2) * G::LPS) : "memory");
-    __builtin_amdgcn_s_barrier();                       // everyone's share landed; buffer (st-1)%NB is free
-    __builtin_amdgcn_sched_barrier(0);
-    issue_stage(st + G::NB - 1);
-    const u32x4* buf = lds16 + (st % G::NB) * G::BUF16;
+    if (it < 0) continue;
+    const u32x4* buf = lds16 + (it % G::NB) * G::BUF16;
 #pragma unroll
     for (int kp = 0; kp < G::KP; ++kp) {
       bf16x8 wf[2], xf[4];
@@ -1188,6 +1242,27 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.res_h = L.res_h ? L.res_h->p : nullptr; a.res_h_nstride = L.res_h ? L.res_h->nstride : 0;
   ah.fuse = 0;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
+  ConcatX cx;
+  cx.nsrc = L.nsrc; cx.p1 = L.p1; cx.p2 = L.p2; cx.cbtot = 0;
+  const uint16_t* xp_[3] = {nullptr, nullptr, nullptr};
+  long xns_[3] = {0, 0, 0};
+  int xcb_[3] = {0, 0x7fffffff, 0x7fffffff}, xcol_[3] = {0, 0, 0};
+  if (L.nsrc) {
+    // concat input: L.x carries the geometry (N, Z, H, W) and the PADDED (even) block count of the virtual tensor
+    if (L.nsrc < 1 || L.nsrc > 3) return hipErrorInvalidValue;
+    int cb = 0;
+    for (int i = 0; i < L.nsrc; ++i) {
+      if (!L.xs[i].p || L.xs[i].Cb < 1) return hipErrorInvalidValue;
+      if (L.xs_collage[i] && (L.p1 < 2 || L.p2 < 2 || L.x.N % ((L.p1 - 1) * (L.p2 - 1)))) return hipErrorInvalidValue;
+      xp_[i] = L.xs[i].p; xns_[i] = L.xs[i].nstride; xcb_[i] = cb; xcol_[i] = L.xs_collage[i];
+      cb += L.xs[i].Cb;
+    }
+    cx.cbtot = cb;
+    if (L.x.Cb != (cb + 1) / 2 * 2) return hipErrorInvalidValue;
+    if (cx.p1 < 2) { cx.p1 = 2; cx.p2 = 2; }              // unused without a collaged source; keeps the index math finite
+  }
+  cx.p0 = xp_[0]; cx.p1p = xp_[1]; cx.p2p = xp_[2]; cx.ns0 = xns_[0]; cx.ns1 = xns_[1]; cx.ns2 = xns_[2];
+  cx.cb1 = xcb_[1]; cx.cb2 = xcb_[2]; cx.col0 = xcol_[0]; cx.col1 = xcol_[1]; cx.col2 = xcol_[2];
   if ((L.x.Cb & 1) || L.x.H != L.x.W || L.y.H != L.x.H || L.y.Z != L.x.Z || L.y.N != L.x.N || (L.flags & EPI_UP2))
     return hipErrorInvalidValue;
   const int TN = conv_bf16_tn(L.Cout);
@@ -1199,13 +1274,16 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
     using G = H1Geo<TN_, NWV_>;                                                                 \
     static DevOnce attr_done;                                                              \
     if (attr_done.need()) {                                                                           \
-      hipError_t e = hipFuncSetAttribute((const void*)conv1_bf16<TN_, NWV_>,                    \
+      hipError_t e = hipFuncSetAttribute((const void*)conv1_bf16<TN_, NWV_, false>,             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv1_bf16<TN_, NWV_, true>,    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
       if (e != hipSuccess) return e;                                                            \
       attr_done.mark();                                                                         \
     }                                                                                           \
     const long grid = ((vox + G::TM - 1) / G::TM) * a.ntile;                                    \
-    hipLaunchKernelGGL((conv1_bf16<TN_, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah, zp); \
+    if (cx.nsrc) hipLaunchKernelGGL((conv1_bf16<TN_, NWV_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah, zp, cx); \
+    else hipLaunchKernelGGL((conv1_bf16<TN_, NWV_, false>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah, zp, cx); \
   } while (0)
   static const int env1 = env_waves("TM_CONV1_WAVES");
   const int fw1 = L.force_waves ? L.force_waves : env1;

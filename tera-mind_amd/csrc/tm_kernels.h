@@ -84,6 +84,12 @@ struct ConvLaunchH {
   int per_image = 1;
   TVH a2;
   int force_waves = 0;              // 0 = auto, 4 | 8 = workgroup form (tests / A-B; TM_CONV27_WAVES, TM_CONV1_WAVES)
+  // conv1 only: input = channel concat of nsrc (1..3) 16-bit CB8 tensors read in place, each optionally through the collage
+  // remap of a (p1 x p2) source patch grid; `x` then only carries N, Z, H, W and the even-padded block count (x.p unused)
+  int nsrc = 0;
+  TVH xs[3];
+  int xs_collage[3] = {0, 0, 0};
+  int p1 = 0, p2 = 0;
 };
 hipError_t init_bf16_device();      // per-device set-up that must not happen lazily inside a stream capture
 hipError_t init_f16_device();

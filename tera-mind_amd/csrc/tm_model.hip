@@ -682,6 +682,8 @@ struct Ctx {
   }
   void check(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
 };
+struct Src { TV t; bool collage; };
+
 // 16-bit view of a stream tensor (16-bit modes only)
 static TVH as_h(const TV& t) {
   TVH v;
@@ -689,7 +691,6 @@ static TVH as_h(const TV& t) {
   return v;
 }
 
-struct Src { TV t; bool collage; };
 
 // Debug taps: with TM_DEBUG_DIR set, every block output is written (NCDHW fp32, raw) to
 // $TM_DEBUG_DIR/<name>.bin after a stream sync.  Test/diagnostic aid only.
@@ -784,11 +785,17 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
 }
 
 static void run_conv1_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, const TV* gate,
-                        int flags, TVH* y_h = nullptr, const TVH* gate_h = nullptr, const TVH* res_h = nullptr) {
+                        int flags, TVH* y_h = nullptr, const TVH* gate_h = nullptr, const TVH* res_h = nullptr,
+                        const std::vector<Src>* concat = nullptr) {
   if (cx.dry) return;
   ConvLaunchH L;
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
   L.gate_h = gate_h; L.res_h = res_h;
+  if (concat) {                       // x = th.cat(sources, 1) (+ to_collage) read in place; `x` carries the geometry only
+    L.nsrc = (int)concat->size();
+    for (int i = 0; i < L.nsrc; ++i) { L.xs[i] = as_h((*concat)[i].t); L.xs_collage[i] = (*concat)[i].collage ? 1 : 0; }
+    L.p1 = cx.p1; L.p2 = cx.p2;
+  }
   if (y_h) { L.y_h = y_h->p; L.yh_nstride = y_h->nstride; }
   cx.check(cx.m->cfg.dtype == TM_DTYPE_F16 ? launch_conv1_f16(L, cx.s) : launch_conv1_bf16(L, cx.s));
 }
@@ -805,7 +812,11 @@ static TV res_block_h16(Ctx& cx, const ResW& w, const std::vector<Src>& src, int
   const size_t mark = cx.top;
   const int cbe = (w.cbi + 1) / 2 * 2;
   TVH Ah = cx.tensor_h(N, cbe, Z, S_out), rawh;
-  const bool need_raw = w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage;
+  // The concatenated / re-tiled x (MBAblocks.py:252-258,297) is only materialised where it is the RESIDUAL of a block
+  // without skip conv (the up / down blocks: resampled x); the skip conv reads the sources in place (conv1's concat input)
+  static const bool ab_raw = getenv("TM_AB_RAW") != nullptr;       // A/B switch: materialise the concat for the skip conv too
+  const bool need_raw = (ab_raw || !w.has_skip) && (w.has_skip || mode != RS_SAME || src.size() > 1 || src[0].collage);
+  if (w.has_skip && mode != RS_SAME) { cx.check(hipErrorInvalidValue); return out; }    // never in this model family
   if (need_raw) rawh = cx.tensor_h(N, cbe, Z, S_out);
   if (!cx.dry) {
     PrepLaunch P;
@@ -847,8 +858,10 @@ static TV res_block_h16(Ctx& cx, const ResW& w, const std::vector<Src>& src, int
   TV rawv = geom; rawv.p = (float*)rawh.p; rawv.nstride = rawh.nstride;   // the residual view of rawh (channels < cout only)
   const TV* r = nullptr;
   if (w.has_skip) {
-    TVH outh = as_h(out);
-    run_conv1_h(cx, rawh, w.skiph, w.skip, out, nullptr, nullptr, 0, &outh);
+    TVH outh = as_h(out), xg = Ah;                       // geometry + padded block count of the virtual concat
+    xg.p = nullptr;
+    if (ab_raw) run_conv1_h(cx, rawh, w.skiph, w.skip, out, nullptr, nullptr, 0, &outh);
+    else run_conv1_h(cx, xg, w.skiph, w.skip, out, nullptr, nullptr, 0, &outh, nullptr, nullptr, &src);
     r = &out;
   } else if (need_raw) r = &rawv;
   else r = &src[0].t;
@@ -1421,6 +1434,61 @@ extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const voi
   if (e0 != hipSuccess) return fail(TM_ERR_HIP, "launch_prep: %s", hipGetErrorString(e0));
   if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv1 (16-bit): %s", hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1 (16-bit) execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}
+extern "C" int tm_op_conv1_concat(const void* const* x_cb8, const int* cin, const int* collage, int nsrc, const void* w_host,
+                                  const void* bias_host, void* y_cb8, int N, int Cout, int Z, int S, int p1, int p2,
+                                  int dtype, int waves, void* stream) {
+  if (!x_cb8 || !cin || !collage || !w_host || !bias_host || !y_cb8 || nsrc < 1 || nsrc > 3) return fail(TM_ERR_ARG, "bad argument");
+  if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
+  const bool f16 = dtype == TM_DTYPE_F16;
+  hipStream_t st = (hipStream_t)stream;
+  bool any_col = false;
+  for (int i = 0; i < nsrc; ++i) any_col = any_col || collage[i];
+  const int q = any_col ? (p1 - 1) * (p2 - 1) : 1;
+  if (any_col && (p1 < 2 || p2 < 2 || N % q)) return fail(TM_ERR_ARG, "collage needs N = b * (p1-1) * (p2-1)");
+  const int Nsrc_col = any_col ? N / q * p1 * p2 : N;      // a collaged source lives on the (p1 x p2) grid
+  std::vector<int> seg(cin, cin + nsrc);
+  int Cbi = 0;
+  for (int c : seg) Cbi += (c + 7) / 8;
+  const int Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64;
+  std::vector<uint16_t> pk(conv1_bf16_pack_elems(Cout, Cbi));
+  (f16 ? conv1_f16_pack_host : conv1_bf16_pack_host)((const float*)w_host, Cout, seg.data(), nsrc, pk.data());
+  std::vector<float> bp((size_t)nt64 * 64, 0.f);
+  memcpy(bp.data(), bias_host, Cout * sizeof(float));
+  const long vox = (long)Z * S * S;
+  uint16_t *dw = nullptr, *dx[3] = {nullptr, nullptr, nullptr};
+  float* db = nullptr;
+  HIP_TRY(hipMalloc((void**)&dw, pk.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMalloc((void**)&db, bp.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  ConvLaunchH L;
+  hipError_t e0 = hipSuccess;
+  for (int i = 0; i < nsrc && e0 == hipSuccess; ++i) {
+    const int Ni = collage[i] ? Nsrc_col : N, cb = (seg[i] + 7) / 8;
+    HIP_TRY(hipMalloc((void**)&dx[i], (size_t)Ni * cb * vox * 8 * sizeof(uint16_t)));
+    TV x = view_cb8(const_cast<void*>(x_cb8[i]), Ni, seg[i], Z, S, S);
+    PrepLaunch P;
+    P.nsrc = 1;
+    P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+    P.N = Ni; P.Z = Z; P.S = S; P.h_f16 = f16 ? 1 : 0;
+    P.out_h = dx[i]; P.out_h_nstride = (long)cb * vox * 8;
+    e0 = launch_prep(P, st);
+    L.xs[i].p = dx[i]; L.xs[i].N = Ni; L.xs[i].Cb = cb; L.xs[i].C = cb * 8; L.xs[i].Z = Z; L.xs[i].H = S; L.xs[i].W = S;
+    L.xs[i].nstride = P.out_h_nstride;
+    L.xs_collage[i] = collage[i] ? 1 : 0;
+  }
+  L.nsrc = nsrc; L.p1 = p1; L.p2 = p2;
+  L.x.p = nullptr; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = Z; L.x.H = S; L.x.W = S; L.x.nstride = 0;
+  L.w = dw; L.bias = db; L.Cout = Cout; L.force_waves = waves;
+  L.y = view_cb8(y_cb8, N, Cout, Z, S, S);
+  hipError_t e = e0 == hipSuccess ? (f16 ? launch_conv1_f16 : launch_conv1_bf16)(L, st) : e0;
+  hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(dw); (void)hipFree(db);
+  for (int i = 0; i < 3; ++i) if (dx[i]) (void)hipFree(dx[i]);
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "conv1 concat launch: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1 concat execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
 extern "C" int tm_op_window_attn(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_dev,

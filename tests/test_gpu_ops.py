@@ -168,6 +168,42 @@ def test_conv1_16bit_stream_epilogue(N, Cin, Cout, Z, S, waves, dtype):
     assert torch.equal(got.cpu(), ref), util.report("conv1 stream " + dtype, got, ref)
 
 
+@pytest.mark.parametrize("b,p1,p2,cins,flags,Cout,S", [
+    (2, 3, 3, (64, 32), (0, 0), 64, 16),              # encoder block: cat(h, rna), plain
+    (1, 2, 4, (128, 64, 32), (1, 1, 1), 128, 8),      # first decoder block of a level: every source re-tiled
+    (2, 3, 2, (40, 24, 229), (0, 1, 1), 512, 8),      # later decoder block: h plain, skip / rna re-tiled; odd block counts
+    (3, 2, 2, (229,), (1,), 192, 8)])
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv1_concat_collage_input_exact_integers(b, p1, p2, cins, flags, Cout, S, waves, dtype):
+    """The skip conv reads th.cat((h, skip, rna), 1) -- and the collage re-tiling of the decoder's sources -- in place
+    (model/unet_ours.py:325-341,384,418): exact-integer check against torch.cat + the oracle's to_collage."""
+    import ctypes as C
+    from oracle import teramind_cpu as tc
+    Nd, Ne = b * (p1 - 1) * (p2 - 1), b * p1 * p2
+    any_col = any(flags)
+    N = Nd if any_col else Ne
+    xs, parts = [], []
+    for i, (c, f) in enumerate(zip(cins, flags)):
+        x = util.rand_int((Ne if f else N, c, 2, S, S), -3, 3, 90 + i)
+        xs.append(x)
+        parts.append(tc.collage(x, b, p1, p2) if f else x)
+    w = util.rand_int((Cout, sum(cins), 1, 1, 1), -2, 2, 95)
+    bias = util.rand_int((Cout,), -4, 4, 96)
+    ref = F.conv3d(torch.cat(parts, 1), w, bias)
+    xc = [util.to_cb8(x.to(DEV)) for x in xs]
+    ptrs = (C.c_void_p * len(xc))(*[t.data_ptr() for t in xc])
+    cin = (C.c_int * len(xc))(*cins)
+    col = (C.c_int * len(xc))(*flags)
+    yc = torch.zeros((N, (Cout + 7) // 8, 2, S, S, 8), dtype=torch.float32, device=DEV)
+    wh, bh = w.contiguous().float(), bias.contiguous().float()
+    _lib.check(_lib.lib().tm_op_conv1_concat(ptrs, cin, col, len(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()),
+                                             _lib.ptr(yc), N, Cout, 2, S, p1, p2, util.H16[dtype][0], waves,
+                                             _lib.current_stream_ptr()), "tm_op_conv1_concat")
+    got = util.from_cb8(yc, Cout)
+    assert torch.equal(got.cpu(), ref), util.report("conv1 concat " + dtype, got, ref)
+
+
 def test_conv27_bf16_random_vs_bf16_rounded_reference():
     g = torch.Generator().manual_seed(17)
     N, Cin, Cout, S = 2, 741, 512, 8
