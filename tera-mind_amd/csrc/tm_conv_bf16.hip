@@ -50,6 +50,13 @@ typedef TM_H16_T h16_t;
 typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));      // 8 x 16-bit floats (bf16 or, with TM_H16_F16, fp16)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector (HIP's uint4 class resists SROA)
 
+// SiLU / tanh-GELU on the hardware exp2 / rcp (1 ulp each) for results that are rounded to a 16-bit type right away
+__device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);          // tanh(u) = 1 - 2 / (1 + e^{2u})
+  return x - x * __frcp_rn(1.0f + __expf(2.0f * u));                           // 0.5 x (1 + tanh u) = x - x / (1 + e^{2u})
+}
+
 struct ConvArgsH {
   ConvArgs c;                 // x / w are reinterpreted: x = bf16 CB8 (elements), w = bf16 packed
   long x_nstride_e, x_plane_e;   // in bf16 elements
@@ -142,8 +149,8 @@ __device__ __forceinline__ void fused_norm_epilogue(const ConvArgsH& ah, f32x16 
           float a0 = w0[j] * (v[j] * rstd[mt]), a1 = w1[j] * (v[4 + j] * rstd[mt]);
           a0 = a0 * (1.0f + sc0[j]) + sh0[j];
           a1 = a1 * (1.0f + sc1[j]) + sh1[j];
-          ob[j] = (h16_t)silu_f(a0);
-          ob[4 + j] = (h16_t)silu_f(a1);
+          ob[j] = (h16_t)silu_fast(a0);
+          ob[4 + j] = (h16_t)silu_fast(a1);
         }
         *(h16x8_t*)(ah.a2 + (long)on[mt] * ah.a2_nstride + (long)cob * a.y_plane + ooff[mt]) = ob;
       }
@@ -196,7 +203,7 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
         }
         if (a.flags & EPI_GELU) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = gelu_tanh_f(o[j]);
+          for (int j = 0; j < 8; ++j) o[j] = a.y_h ? gelu_tanh_fast(o[j]) : gelu_tanh_f(o[j]);
         }
         if (GATE && a.gate_h) {
 #pragma unroll

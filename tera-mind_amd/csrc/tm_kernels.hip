@@ -609,7 +609,9 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         r[j] += v;
         if (L.norm_w) v = wn[j] * (v * rstd[sub]);
         if (L.mod != MOD_NONE) v = v * (1.0f + sc[j]) + sh[j];
-        if (L.act) v = silu_f(v);
+        // SiLU: exact expf / division where the result stays fp32; hardware exp2 / rcp (1 ulp) where it is rounded to a
+        // 16-bit type anyway (the 16-bit modes: 8 or 11 significant bits survive)
+        if (L.act) v = L.out_h ? v * __frcp_rn(1.0f + __expf(-v)) : silu_f(v);
         o[j] += v;
       }
     }
