@@ -524,6 +524,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   static_assert(G::WPIECES <= G::WSLOTS && G::XPIECES % NT == 0 && G::WSLOTS % NT == 0, "staging shape");
   const ConvArgs& a = ah.c;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+#ifdef TM_STAMPS
+  unsigned long long* stamp_slot = nullptr;
+  if (threadIdx.x == 0 && g_tm_stamps) {
+    const unsigned int k = atomicAdd(&g_tm_stamp_next, 1u);
+    if (k < g_tm_stamp_cap) {
+      stamp_slot = g_tm_stamps + (size_t)k * 8;
+      stamp_slot[4] = gridDim.x; stamp_slot[5] = blockIdx.x;
+      stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + 500000ull + (unsigned long long)(TN * 1000 + NWV * 10 + (MS ? 1 : 0));
+      stamp_slot[7] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  TM_STAMP(0);
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int i32 = lane & 31, h = lane >> 5;
@@ -609,6 +622,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   // whatever the stage is: the ring fill, the steady state and the dummy tail are the same code, at ONE site -- a
   // capturing lambda used from two places kept every captured local, the kernel arguments included, in scratch) and then,
   // for it >= 0, computes stage `it`.
+  TM_STAMP(1);
   for (int it = -(G::NB - 1); it < NS; ++it) {
     if (it >= 0) {
       // stage `it` has landed once at most (NB-2) younger stages of this wave are still in flight
@@ -671,7 +685,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail's dummy DMAs before the LDS is released
+  TM_STAMP(2);
   conv_epilogue_h16<true>(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
+#ifdef TM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TM_STAMP(3);
+#endif
 }
 
 

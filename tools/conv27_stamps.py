@@ -57,11 +57,12 @@ def main():
         pro, loop, epi = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
         life = s[:, 3] - s[:, 0]
         cbp, rest = divmod(tag, 1000000)
-        tn, rest = divmod(rest, 1000)
+        is1 = rest >= 500000                                           # conv1 (1x1x1 / Linear) launch
+        tn, rest = divmod(rest - (500000 if is1 else 0), 1000)
         tw, fuse = divmod(rest, 10)
-        nh = 2 * cbp
+        nh = (cbp + (tn // 64) - 1) // (tn // 64) if is1 else 2 * cbp   # conv1: stages of KP = TN/64 pairs
         span_us = (s[:, 7].max() - s[:, 7].min()) / 100.0              # s_memrealtime: 100 MHz
-        out.append({"TN": tn, "TW": tw, "fuse": fuse, "pairs": cbp, "stages": nh, "wgs": int(j - i), "grid": grid,
+        out.append({"kind": "conv1" if is1 else "conv27", "TN": tn, "TW": tw, "fuse": fuse, "pairs": cbp, "stages": nh, "wgs": int(j - i), "grid": grid,
                     "prologue": float(np.median(pro)), "loop": float(np.median(loop)), "loop_per_stage": float(np.median(loop)) / nh,
                     "epilogue": float(np.median(epi)), "life": float(np.median(life)),
                     "epilogue_p90": float(np.percentile(epi, 90)), "prologue_p90": float(np.percentile(pro, 90)),
@@ -71,10 +72,13 @@ def main():
           f"{'pro%':>5s} {'loop%':>6s} {'epi%':>5s} | ideal/stage 4608 (8 waves) or 2304x2 (4 waves)")
     tot = {"pro": 0.0, "loop": 0.0, "epi": 0.0, "ideal": 0.0}
     for r in out:
-        print(f"{r['TN']:4d} {r['TW']:3d} {r['fuse']:1d} {r['pairs']:5d} {r['wgs']:6d} | {r['prologue']:9.0f} {r['loop']:9.0f} {r['loop_per_stage']:7.0f} "
+        print(("c1 " if r["kind"] == "conv1" else "c27") + f"{r['TN']:4d} {r['TW']:3d} {r['fuse']:1d} {r['pairs']:5d} {r['wgs']:6d} | {r['prologue']:9.0f} {r['loop']:9.0f} {r['loop_per_stage']:7.0f} "
               f"{r['epilogue']:9.0f} {r['life']:9.0f} | {100 * r['prologue'] / r['life']:5.1f} {100 * r['loop'] / r['life']:6.1f} "
               f"{100 * r['epilogue'] / r['life']:5.1f}")
-        tot["pro"] += r["prologue"] * r["wgs"]; tot["loop"] += r["loop"] * r["wgs"]; tot["epi"] += r["epilogue"] * r["wgs"]
+        if r["kind"] == "conv27":
+            tot["pro"] += r["prologue"] * r["wgs"]; tot["loop"] += r["loop"] * r["wgs"]; tot["epi"] += r["epilogue"] * r["wgs"]
+        if r["kind"] == "conv1":
+            continue
         tot["ideal"] += 4608.0 * r["stages"] * r["wgs"]
     s_ = tot["pro"] + tot["loop"] + tot["epi"]
     print(f"workgroup-cycles: prologue {100 * tot['pro'] / s_:.1f} %  main loop {100 * tot['loop'] / s_:.1f} %  epilogue {100 * tot['epi'] / s_:.1f} %;"
