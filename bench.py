@@ -219,11 +219,21 @@ def worker(args):
         shape_only = torch.empty((b, C, ps * P, ps * P), device="meta")
         tmap = torch.tensor(smp.timestep_map, dtype=torch.int64, device=dev)
 
+        pyr = {}
+
         def one_step(k, state):
             i = T_STEPS - 1 - (k % T_STEPS)
             xp = pad_patchify(state, ps)
             t = tmap[i].expand(b).contiguous()
-            eps = model(x=xp, t=t, rna=rna, imgs=shape_only, patch_size=ps).pred
+            cond = rna
+            if not args.tile:
+                # mode A (configs[1]: the 50-step sample loop of SpacedDiffusionBeatGans.sample): the RNA conditioning
+                # pyramid is computed once per sample of T = 50 steps, as the sampler does it; the first step of the timed
+                # region recomputes it, so the K timed steps carry one such computation (50 / K times its real share)
+                if k % T_STEPS == 0 or k == args.warmup or "p" not in pyr:
+                    pyr["p"] = model.precompute_rna(rna, b, imgs=shape_only, patch_size=ps)
+                cond = pyr["p"]
+            eps = model(x=xp, t=t, rna=cond, imgs=shape_only, patch_size=ps).pred
             return sampler_step(smp, i, xp, eps, noise[k % 4] if gen == "ddpm" else None, b, P, P)
 
         state = img

@@ -107,6 +107,21 @@ int tm_unet_forward(tm_model* m, const void* x, const int64_t* t, const void* rn
                     int b, int p1, int p2, void* pred, void* pred2_or_null,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* The RNA conditioning of a forward (BeatGANsUNetModel.get_rna, model/unet_ours.py:298-323: gene-gene attention block,
+ * down_z, the three pyramid convs) depends on the genes only -- not on x or t.  A caller that runs many diffusion steps on
+ * the same genes (mode A: LitModel.gen_sample's reverse loop, experiment.py:325-330; the reference recomputes it in every
+ * step) computes it ONCE into a buffer of its own and hands it to every step:
+ *   tm_rna_pyramid_bytes   size of that buffer for (b, p1, p2)
+ *   tm_rna_pyramid         rna_dense [b*p1*p2, gn, gn, rna_slc*500] fp32 -> pyramid (opaque; valid for this model, b, p1, p2)
+ *   tm_unet_forward_rna    tm_unet_forward with the precomputed pyramid in place of rna_dense; bit-identical results.
+ * The pyramid buffer is only read by tm_unet_forward_rna and may be shared by any number of steps. */
+size_t tm_rna_pyramid_bytes(const tm_model* m, int b, int p1, int p2);
+int tm_rna_pyramid(tm_model* m, const void* rna_dense, int b, int p1, int p2, void* pyramid, size_t pyramid_bytes,
+                   void* stream);
+int tm_unet_forward_rna(tm_model* m, const void* x, const int64_t* t, const void* pyramid, size_t pyramid_bytes,
+                        int b, int p1, int p2, void* pred, void* pred2_or_null, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* Per-step scalar coefficients: the float64 tables of GaussianDiffusionBeatGans.__init__
  * (diffusion/base.py:64-109) gathered at index i and cast `.float()` (base.py:643) by
  * the host. */

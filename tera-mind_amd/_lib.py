@@ -48,6 +48,10 @@ SIGNATURES = {
     "tm_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
     "tm_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tm_rna_pyramid_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "tm_rna_pyramid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "tm_unet_forward_rna": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tm_sampler_step": (c_int, [C.POINTER(TmStepCoefs), c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "tm_pad_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

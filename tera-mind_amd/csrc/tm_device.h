@@ -86,6 +86,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
   // ooff: in-plane float offset of the voxel in the OUTPUT plane geometry (or -1)
 #pragma unroll
   for (int ct = 0; ct < WN; ++ct) {
+    // (1) the residual / gate quads of this 32-cout slice of the wave tile are requested up front with UNCONDITIONAL loads
+    //     (lanes without a valid voxel / cout block read element 0 of the tensor): 4 * WM (x2 with a gate) independent
+    //     16-byte loads in flight instead of as many load -> use -> store chains behind per-voxel branches
+    f32x4 rv[4][WM], gv[4][WM];
+    bool ok[4][WM];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cob = nt * (4 * WN) + ct * 4 + g;
+#pragma unroll
+      for (int mt = 0; mt < WM; ++mt) {
+        ok[g][mt] = cob < a.Cob && ooff[mt] >= 0;
+        const long pl = ok[g][mt] ? (long)cob * a.y_plane + ooff[mt] + 4 * h : 0;
+        if (a.res) rv[g][mt] = *(const f32x4*)(a.res + (ok[g][mt] ? (long)on[mt] * a.res_nstride : 0) + pl);
+        if (a.gate) gv[g][mt] = *(const f32x4*)(a.gate + (ok[g][mt] ? (long)on[mt] * a.gate_nstride : 0) + pl);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int cob = nt * (4 * WN) + ct * 4 + g;
@@ -93,7 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
       const f32x4 bv = *(const f32x4*)(a.bias + (long)cob * 8 + 4 * h);
 #pragma unroll
       for (int mt = 0; mt < WM; ++mt) {
-        if (ooff[mt] < 0) continue;
+        if (!ok[g][mt]) continue;
         f32x4 o;
         o[0] = acc[ct][mt][4 * g + 0] + bv[0];
         o[1] = acc[ct][mt][4 * g + 1] + bv[1];
@@ -105,18 +122,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
         }
         const long pl = (long)cob * a.y_plane + ooff[mt] + 4 * h;
         if (a.gate) {
-          const f32x4 gv = *(const f32x4*)(a.gate + (long)on[mt] * a.gate_nstride + pl);
-          o *= gv;
+          o *= gv[g][mt];
         } else if (a.gate_h) {
           typedef TM_H16_T bf16x4_g __attribute__((ext_vector_type(4)));
           const bf16x4_g gb = *(const bf16x4_g*)(a.gate_h + (long)on[mt] * a.gate_h_nstride + pl);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] *= (float)gb[j];
         }
-        if (a.res) {
-          const f32x4 rv = *(const f32x4*)(a.res + (long)on[mt] * a.res_nstride + pl);
-          o = rv + o;
-        }
+        if (a.res) o = rv[g][mt] + o;
         if (a.y_h) {
           typedef TM_H16_T bf16x4_t __attribute__((ext_vector_type(4)));
           bf16x4_t ob;

@@ -1039,11 +1039,86 @@ static void run_direct(Ctx& cx, const DirectW& w, const float* x, Acc5 ax, float
   cx.check(launch_conv_direct(L, cx.s));
 }
 
-static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* rna, float* pred, float* pred2) {
+// The RNA conditioning of a call (get_rna, model/unet_ours.py:298-323): four pyramid levels (stream tensors: fp32, or 16-bit
+// in the 16-bit modes) and, in fp32 mode, SiLU(level) of the first three (pyramid conv input and adaLN input of the
+// non-re-tiled AttnBlocks).  It depends on the genes only, not on t or x: a sampler that runs many steps on the same genes
+// (mode A, LitModel.gen_sample) computes it once (tm_rna_pyramid) and hands it to every step (tm_unet_forward_rna).
+struct RnaOut { TV rl[4]; TV rs[3]; };
+
+// Allocates the persistent outputs FIRST (so that their layout inside a caller-provided pyramid buffer is a pure function
+// of (b, p1, p2)), computes them, and releases the scratch.  rna == nullptr: layout only.
+static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
+  tm_model* m = cx.m;
+  const tm_config& c = m->cfg;
+  const int Z = m->z, Ne = cx.Ne;
+  const bool h16 = is_h16(c.dtype), run = !cx.dry && rna != nullptr;
+  int S = m->gn * 2;
+  for (int i = 0; i < 4; ++i) { R.rl[i] = cx.tensor_s(Ne, m->rw[i], Z, S); S *= 2; }
+  S = m->gn * 2;
+  if (!h16) for (int i = 0; i < 3; ++i) { R.rs[i] = cx.tensor(Ne, m->rw[i], Z, S); S *= 2; }
+  const size_t rna_mark = cx.top;
+  TV tok = cx.tensor(Ne, c.rna_num, c.rna_slc, m->gn);           // gene-attention output, CB8 [Ne][Gb][zs][gn][gn][8]
+  if (run) {
+    cx.check(hipMemsetAsync(tok.p, 0, (size_t)Ne * tok.nstride * sizeof(float), cx.s));      // pad gene slots
+    if (m->gene_mfma)
+      cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok.p, nullptr, 0, c.rna_slc, cx.s));
+  }
+  if (!m->gene_mfma) {
+    const size_t mark = cx.top;
+    float* gws = cx.alloc_f((size_t)Ne * gene_generic_split(Ne) * gene_generic_ws_floats(c.rna_num, m->D));
+    if (run)
+      cx.check(launch_gene_attn_generic(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->D, m->gene, m->gene_idx, tok.p, nullptr, 0,
+                                        c.rna_slc, gws, cx.s));
+    cx.top = mark;                                               // scratch only (the stream orders its reuse)
+  }
+  // fp32 levels: the outputs themselves in fp32 mode, scratch in the 16-bit modes (the RNA path stays fp32: 0.2 % of the FLOPs)
+  TV rl[4], rs[3];
+  S = m->gn * 2;
+  for (int i = 0; i < 4; ++i) { rl[i] = h16 ? cx.tensor(Ne, m->rw[i], Z, S) : R.rl[i]; S *= 2; }
+  S = m->gn * 2;
+  for (int i = 0; i < 3; ++i) { rs[i] = h16 ? cx.tensor(Ne, m->rw[i], Z, S) : R.rs[i]; S *= 2; }
+  const bool was_dry = cx.dry;
+  cx.dry = !run;
+  if (m->downz_mfma) run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
+  else {
+    // generic (kz, gn): direct conv straight from / to the CB8 tensors, nearest x2 fused into the store
+    const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl[0]);
+    if (run) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));   // pad channels
+    run_direct(cx, m->downz_d, tok.p, ax, rl[0].p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+  }
+  for (int i = 1; i < 4; ++i) {
+    if (run) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = rl[i - 1].p; P.src[0].nstride = rl[i - 1].nstride; P.src[0].Cb = rl[i - 1].Cb;
+      P.N = Ne; P.Z = Z; P.S = rl[i - 1].H; P.act = 1;
+      P.out = rs[i - 1].p; P.out_nstride = rs[i - 1].nstride;
+      cx.check(launch_prep(P, cx.s));
+    }
+    run_conv(cx, rs[i - 1], m->pyr[i - 1], rl[i], nullptr, nullptr, EPI_UP2, 0, ZM_INPLANE);   // SiLU -> conv -> Upsample
+  }
+  if (h16 && run) {                                               // the four levels enter the 16-bit activation stream here
+    for (int i = 0; i < 4; ++i) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = rl[i].p; P.src[0].nstride = rl[i].nstride; P.src[0].Cb = rl[i].Cb;
+      P.N = Ne; P.Z = Z; P.S = rl[i].H; P.h_f16 = c.dtype == TM_DTYPE_F16;
+      P.out_h = (uint16_t*)R.rl[i].p; P.out_h_nstride = R.rl[i].nstride;
+      cx.check(launch_prep(P, cx.s));
+    }
+  }
+  cx.dry = was_dry;
+  cx.top = rna_mark;                                              // tok / fp32 scratch are dead (the stream orders reuse)
+}
+
+// rna != nullptr: compute the conditioning inside this call's workspace; otherwise R_in (tm_rna_pyramid) is used
+static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* rna, const RnaOut* R_in, float* pred,
+                        float* pred2) {
   tm_model* m = cx.m;
   const tm_config& c = m->cfg;
   const int Z = m->z, L = m->L, ps = c.patch_size, Ne = cx.Ne, Nd = cx.Nd, b = cx.b;
   const int ne_img = cx.p1 * cx.p2, nd_img = (cx.p1 - 1) * (cx.p2 - 1);
+  const bool h16 = is_h16(c.dtype);
   // ---- time embedding + all emb_layers ----
   float* te = cx.alloc_f((size_t)b * c.embed_ch);
   float* ss = cx.alloc_f((size_t)b * m->emb_tot);
@@ -1052,67 +1127,12 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
     cx.check(launch_time_embed(t, b, c.net_ch, c.embed_ch, m->te_w1, m->te_b1, m->te_w2, m->te_b2, te, cx.s));
     cx.check(launch_emb_all(te, b, c.embed_ch, m->emb_w, m->emb_b, m->emb_tot, ss, cx.s));
   }
-  // ---- RNA pyramid (get_rna, model/unet_ours.py:298-323) ----
-  const bool h16 = is_h16(c.dtype);
-  TV rl16[4];
-  if (h16) {                                                      // 16-bit stream copies of the four levels (persist for the call)
-    int S16 = m->gn * 2;
-    for (int i = 0; i < 4; ++i) { rl16[i] = cx.tensor_s(Ne, m->rw[i], Z, S16); S16 *= 2; }
-  }
-  const size_t rna_mark = cx.top;
-  TV tok = cx.tensor(Ne, c.rna_num, c.rna_slc, m->gn);           // gene-attention output, CB8 [Ne][Gb][zs][gn][gn][8]
-  if (!cx.dry) {
-    cx.check(hipMemsetAsync(tok.p, 0, (size_t)Ne * tok.nstride * sizeof(float), cx.s));      // pad gene slots
-    if (m->gene_mfma)
-      cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok.p, nullptr, 0, c.rna_slc, cx.s));
-  }
-  if (!m->gene_mfma) {
-    const size_t mark = cx.top;
-    float* gws = cx.alloc_f((size_t)Ne * gene_generic_split(Ne) * gene_generic_ws_floats(c.rna_num, m->D));
-    if (!cx.dry)
-      cx.check(launch_gene_attn_generic(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->D, m->gene, m->gene_idx, tok.p, nullptr, 0,
-                                        c.rna_slc, gws, cx.s));
-    cx.top = mark;                                               // scratch only (the stream orders its reuse)
-  }
-  TV rl[4], rs[3];                                               // rna levels and SiLU(level) (pyramid + adaLN input)
-  int S = m->gn * 2;
-  rl[0] = cx.tensor(Ne, m->rw[0], Z, S);
-  if (m->downz_mfma) run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
-  else {
-    // generic (kz, gn): direct conv straight from / to the CB8 tensors, nearest x2 fused into the store
-    const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl[0]);
-    if (!cx.dry) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));   // pad channels
-    run_direct(cx, m->downz_d, tok.p, ax, rl[0].p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
-  }
-  for (int i = 1; i < 4; ++i) {
-    rs[i - 1] = cx.tensor(Ne, m->rw[i - 1], Z, S);
-    if (!cx.dry) {
-      PrepLaunch P;
-      P.nsrc = 1;
-      P.src[0].p = rl[i - 1].p; P.src[0].nstride = rl[i - 1].nstride; P.src[0].Cb = rl[i - 1].Cb;
-      P.N = Ne; P.Z = Z; P.S = S; P.act = 1;
-      P.out = rs[i - 1].p; P.out_nstride = rs[i - 1].nstride;
-      cx.check(launch_prep(P, cx.s));
-    }
-    rl[i] = cx.tensor(Ne, m->rw[i], Z, S * 2);
-    run_conv(cx, rs[i - 1], m->pyr[i - 1], rl[i], nullptr, nullptr, EPI_UP2, 0, ZM_INPLANE);   // SiLU -> conv -> Upsample
-    S *= 2;
-  }
-  if (h16) {
-    // the RNA path itself stays fp32 (0.2 % of the FLOPs); its four levels enter the 16-bit activation stream here
-    for (int i = 0; i < 4; ++i) {
-      if (!cx.dry) {
-        PrepLaunch P;
-        P.nsrc = 1;
-        P.src[0].p = rl[i].p; P.src[0].nstride = rl[i].nstride; P.src[0].Cb = rl[i].Cb;
-        P.N = Ne; P.Z = Z; P.S = rl[i].H; P.h_f16 = c.dtype == TM_DTYPE_F16;
-        P.out_h = (uint16_t*)rl16[i].p; P.out_h_nstride = rl16[i].nstride;
-        cx.check(launch_prep(P, cx.s));
-      }
-      rl[i] = rl16[i];
-    }
-    cx.top = rna_mark;                                            // the fp32 levels and their scratch are dead
-  }
+  // ---- RNA pyramid ----
+  RnaOut Rloc;
+  if (!R_in) { rna_stage(cx, rna, Rloc); R_in = &Rloc; }
+  TV rl[4], rs[3];
+  for (int i = 0; i < 4; ++i) rl[i] = R_in->rl[i];
+  for (int i = 0; i < 3; ++i) rs[i] = R_in->rs[i];
   for (int i = 0; i < 4; ++i) { TV v = rl[i]; v.C = m->rw[i]; dump_tv(cx, "rna." + std::to_string(i), v); }
   // ---- stem ----
   std::vector<std::vector<TV>> skips(L);
@@ -1199,7 +1219,7 @@ extern "C" size_t tm_workspace_bytes(const tm_model* m, int b, int p1, int p2, i
   Ctx cx;
   cx.m = const_cast<tm_model*>(m); cx.dry = true;
   cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
-  forward_impl(cx, nullptr, nullptr, nullptr, (float*)256, want_pred2 ? (float*)256 : nullptr);
+  forward_impl(cx, nullptr, nullptr, nullptr, nullptr, (float*)256, want_pred2 ? (float*)256 : nullptr);
   return cx.peak + 256;
 }
 
@@ -1216,7 +1236,62 @@ extern "C" int tm_unet_forward(tm_model* m, const void* x, const int64_t* t, con
   cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
   const size_t need = tm_workspace_bytes(m, b, p1, p2, pred2_or_null != nullptr);
   if (workspace_bytes < need) return fail(TM_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
-  forward_impl(cx, (const float*)x, t, (const float*)rna_dense, (float*)pred, (float*)pred2_or_null);
+  forward_impl(cx, (const float*)x, t, (const float*)rna_dense, nullptr, (float*)pred, (float*)pred2_or_null);
+  if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
+  return TM_OK;
+}
+
+// ---- RNA conditioning computed once for many steps (mode A: the genes do not change over the reverse loop) ----
+static void pyramid_ctx(Ctx& cx, tm_model* m, int b, int p1, int p2, void* buf, size_t bytes, hipStream_t s) {
+  cx.m = m; cx.s = s;
+  cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
+  if (buf) {
+    cx.base = (char*)(((uintptr_t)buf + 255) / 256 * 256);
+    cx.cap = bytes - (size_t)(cx.base - (char*)buf);
+  } else cx.dry = true;
+}
+extern "C" size_t tm_rna_pyramid_bytes(const tm_model* m, int b, int p1, int p2) {
+  if (check_fwd_args(m, b, p1, p2) != TM_OK) return 0;
+  Ctx cx;
+  pyramid_ctx(cx, const_cast<tm_model*>(m), b, p1, p2, nullptr, 0, nullptr);
+  RnaOut R;
+  rna_stage(cx, nullptr, R);
+  return cx.peak + 512;
+}
+extern "C" int tm_rna_pyramid(tm_model* m, const void* rna_dense, int b, int p1, int p2, void* pyramid, size_t pyramid_bytes,
+                              void* stream) {
+  int rc = check_fwd_args(m, b, p1, p2);
+  if (rc != TM_OK) return rc;
+  if (!rna_dense || !pyramid) return fail(TM_ERR_ARG, "null tensor argument");
+  const size_t need = tm_rna_pyramid_bytes(m, b, p1, p2);
+  if (pyramid_bytes < need) return fail(TM_ERR_WORKSPACE, "pyramid buffer %zu B < required %zu B", pyramid_bytes, need);
+  Ctx cx;
+  pyramid_ctx(cx, m, b, p1, p2, pyramid, pyramid_bytes, (hipStream_t)stream);
+  RnaOut R;
+  rna_stage(cx, (const float*)rna_dense, R);
+  if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
+  return TM_OK;
+}
+extern "C" int tm_unet_forward_rna(tm_model* m, const void* x, const int64_t* t, const void* pyramid, size_t pyramid_bytes,
+                                   int b, int p1, int p2, void* pred, void* pred2_or_null, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  int rc = check_fwd_args(m, b, p1, p2);
+  if (rc != TM_OK) return rc;
+  if (!x || !t || !pyramid || !pred || !workspace) return fail(TM_ERR_ARG, "null tensor argument");
+  if (pyramid_bytes < tm_rna_pyramid_bytes(m, b, p1, p2)) return fail(TM_ERR_WORKSPACE, "pyramid buffer too small for (b, p1, p2)");
+  // the layout of the persistent tensors inside the pyramid buffer is a pure function of (b, p1, p2): replay it
+  Ctx px;
+  pyramid_ctx(px, m, b, p1, p2, const_cast<void*>(pyramid), pyramid_bytes, (hipStream_t)stream);
+  RnaOut R;
+  rna_stage(px, nullptr, R);
+  Ctx cx;
+  cx.m = m; cx.s = (hipStream_t)stream;
+  cx.base = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+  cx.cap = workspace_bytes - (size_t)(cx.base - (char*)workspace);
+  cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
+  const size_t need = tm_workspace_bytes(m, b, p1, p2, pred2_or_null != nullptr);      // upper bound (it includes the RNA scratch)
+  if (workspace_bytes < need) return fail(TM_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  forward_impl(cx, (const float*)x, t, nullptr, &R, (float*)pred, (float*)pred2_or_null);
   if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
   return TM_OK;
 }

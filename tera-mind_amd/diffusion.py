@@ -219,6 +219,10 @@ class SpacedDiffusionBeatGans:
             r_sz = ps // ((H + ps) // rna[2][1])                              # base.py:594
             rna_new = sparse_repatch(rna, r_sz)
         shape_only = torch.empty((b, c, H, W), device="meta")                 # model reads imgs.shape only
+        if len(indices) > 1 and hasattr(model, "precompute_rna"):
+            # mode A: the genes are the same in every step of the reverse loop; the reference recomputes get_rna
+            # (unet_ours.py:376) per step, here the conditioning pyramid is computed once (bit-identical results)
+            rna_new = model.precompute_rna(rna_new, b, imgs=shape_only, patch_size=ps)
         for k, i in enumerate(indices):
             t = torch.full((b,), self.timestep_map[i], dtype=torch.int64, device=device)   # _WrappedModel, diffusion.py:140-147
             x_patches = pad_patchify(img, ps) if img_patch is None else img_patch.to(device).float().contiguous()

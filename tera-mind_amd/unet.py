@@ -132,7 +132,33 @@ class _CudaArray:
                                          "version": 2, "strides": None}
 
 
+class RnaPyramid:
+    """The RNA conditioning of a forward, computed once (BeatGANsUNetModel.precompute_rna) for the many steps of a reverse
+    loop over the same genes.  Opaque device buffer + the (b, p1, p2) it is valid for."""
+
+    def __init__(self, buf: torch.Tensor, b: int, p1: int, p2: int):
+        self.buf, self.b, self.p1, self.p2 = buf, b, p1, p2
+
+
 class BeatGANsUNetModel(_HipModel):
+    def precompute_rna(self, rna, b: int, imgs=None, patch_size=64) -> RnaPyramid:
+        """get_rna (unet_ours.py:298-323) for `b` images whose padded patch grid is taken from `imgs.shape[-2:]`: depends
+        on the genes only, so a T-step sampler calls it once and passes the result as `rna=` to every step."""
+        if not self._finalized:
+            raise RuntimeError("load_state_dict() must be called before precompute_rna")
+        H, W = imgs.shape[-2:]
+        p1, p2 = H // patch_size + 1, W // patch_size + 1
+        rna_d = densify_rna(rna, self.device)
+        gn, zg = self.conf.gn_sz, self.conf.rna_slc * 500
+        if tuple(rna_d.shape) != (b * p1 * p2, gn, gn, zg):
+            raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(b * p1 * p2, gn, gn, zg)}")
+        with torch.cuda.device(self.device):
+            n = self._L.tm_rna_pyramid_bytes(self._h, b, p1, p2)
+            buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+            _lib.check(self._L.tm_rna_pyramid(self._h, _lib.ptr(rna_d), b, p1, p2, _lib.ptr(buf), n, _lib.current_stream_ptr()),
+                       "tm_rna_pyramid")
+        return RnaPyramid(buf, b, p1, p2)
+
     def forward(self, x, t, rna=None, pos=None, y=None, imgs=None, cond=None, noise=None, t_cond=None,
                 idx=None, index=None, do_train=False, patch_size=64, pos_random=None, random=None,
                 want_pred2=False, **kwargs):
@@ -155,18 +181,28 @@ class BeatGANsUNetModel(_HipModel):
         C_ = self.conf.in_channels
         if tuple(x.shape) != (ne, C_, patch_size, patch_size):
             raise ValueError(f"x has shape {tuple(x.shape)}, expected {(ne, C_, patch_size, patch_size)}")
-        rna_d = densify_rna(rna, self.device)
-        gn, zg = self.conf.gn_sz, self.conf.rna_slc * 500
-        if tuple(rna_d.shape) != (ne, gn, gn, zg):
-            raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(ne, gn, gn, zg)}")
+        pyr = rna if isinstance(rna, RnaPyramid) else None
+        if pyr is not None:
+            if (pyr.b, pyr.p1, pyr.p2) != (b, p1, p2):
+                raise ValueError(f"RnaPyramid was computed for (b, p1, p2) = {(pyr.b, pyr.p1, pyr.p2)}, this call has {(b, p1, p2)}")
+        else:
+            rna_d = densify_rna(rna, self.device)
+            gn, zg = self.conf.gn_sz, self.conf.rna_slc * 500
+            if tuple(rna_d.shape) != (ne, gn, gn, zg):
+                raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(ne, gn, gn, zg)}")
         pred = torch.empty((nd, C_, patch_size, patch_size), dtype=torch.float32, device=self.device)
         pred2 = torch.empty_like(x) if want_pred2 else None
         with torch.cuda.device(self.device):
             need = self._L.tm_workspace_bytes(self._h, b, p1, p2, int(want_pred2))
             ws = self._workspace(need)
-            _lib.check(self._L.tm_unet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(rna_d), b, p1, p2,
-                                               _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
-                                               _lib.current_stream_ptr()), "tm_unet_forward")
+            if pyr is not None:
+                _lib.check(self._L.tm_unet_forward_rna(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(pyr.buf), pyr.buf.numel(), b, p1, p2,
+                                                       _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+                                                       _lib.current_stream_ptr()), "tm_unet_forward_rna")
+            else:
+                _lib.check(self._L.tm_unet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(rna_d), b, p1, p2,
+                                                   _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream_ptr()), "tm_unet_forward")
         return AutoencReturn(pred=pred, pred2=pred2, cond=cond)
 
 
@@ -198,4 +234,4 @@ def make_model(conf: PathConfig, device="cuda:0", state_dict=None, vis_only=Fals
     return m
 
 
-__all__ = ["AutoencReturn", "BeatGANsUNetModel", "GeneAttnModel", "make_model", "param_spec"]
+__all__ = ["AutoencReturn", "RnaPyramid", "BeatGANsUNetModel", "GeneAttnModel", "make_model", "param_spec"]

@@ -210,3 +210,24 @@ def test_forward_argument_validation():
         BeatGANsUNetModel(PathConfig(), DEV)(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(1, 4, 64, 64))
     with pytest.raises(RuntimeError):
         BeatGANsUNetModel(PathConfig(), DEV).load_state_dict({"bogus.key": torch.zeros(1)})
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_precomputed_rna_pyramid_is_bit_identical(dtype):
+    """tm_rna_pyramid + tm_unet_forward_rna (the RNA conditioning computed once for the steps of a reverse loop) return
+    the bits of tm_unet_forward, which recomputes it per call like the reference (unet_ours.py:376); the sampler's mode-A
+    loop uses it (diffusion.sample_progressive)."""
+    cfg = PathConfig(compute_dtype=dtype)
+    m = hip_model() if dtype == "f32" else BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    b, P = 2, 2
+    x, t, rna = make_inputs(b, P, seed=9)
+    shp = torch.zeros(b, 4, 64 * P, 64 * P)
+    a = m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=shp, patch_size=64, want_pred2=True)
+    pyr = m.precompute_rna(rna.to(DEV), b, imgs=shp, patch_size=64)
+    for tt in (t, torch.tensor([5, 990])):
+        ref = m(x=x.to(DEV), t=tt.to(DEV), rna=rna.to(DEV), imgs=shp, patch_size=64, want_pred2=True)
+        got = m(x=x.to(DEV), t=tt.to(DEV), rna=pyr, imgs=shp, patch_size=64, want_pred2=True)
+        assert torch.equal(got.pred, ref.pred) and torch.equal(got.pred2, ref.pred2)
+    assert torch.equal(a.pred, m(x=x.to(DEV), t=t.to(DEV), rna=pyr, imgs=shp, patch_size=64).pred)
+    with pytest.raises(ValueError):
+        m(x=x[:9].to(DEV), t=t[:1].to(DEV), rna=pyr, imgs=torch.zeros(1, 4, 128, 128), patch_size=64)
