@@ -259,6 +259,33 @@ int tm_op_conv_direct(const void* x, const void* w_host, const void* bias_host, 
                       int Cin, int Cout, int Zin, int S, int kz, int ky, int kx, int pz, int py,
                       int px, int silu_in, int up2_out, void* stream);
 
+/* ---- training slice: the pieces of ONE ResBlock's training step ---------------------------------
+ * ResBlock._forward in training mode (model/MBAblocks.py:237-299) is
+ *   A = SiLU(RMSNorm(x) w1);  H1 = Conv3d(A);  D = Dropout(SiLU(RMSNorm(H1) w2 (1 + scale) + shift));  out = skip(x) + Conv3d(D)
+ * and its backward is composed of the entry points below (teramind_amd.training.ResBlockTrain does the composition; the
+ * gradient of every piece is checked against torch.autograd of the oracle, tests/test_gpu_train.py).  fp32, CB8 tensors. */
+
+/* y = Dropout(SiLU(RMSNorm_C(x) * norm_w * (1 + scale[img]) + shift[img])) with a SUPPLIED keep mask (fp32 CB8 0/1, or NULL
+ * = no dropout; nn.Dropout(p=0.1) draws it in the reference, config_parm.py:46) and drop_scale = 1 / (1 - p).
+ * norm_w [C], scale / shift [ceil(N / per_image)][C] HOST (or both NULL: in_layers). */
+int tm_op_prep_train(const void* x_cb8, const void* norm_w_host, const void* scale_host, const void* shift_host,
+                     const void* mask_cb8, float drop_scale, int per_image, void* y_cb8, int N, int C, int Z, int S,
+                     void* stream);
+
+/* Backward of the above: g = dL/dy (CB8) -> dx (CB8), dL/dnorm_w [C], dL/dscale, dL/dshift [nimg][C] (HOST outputs). */
+int tm_op_prep_bwd(const void* x_cb8, const void* g_cb8, const void* norm_w_host, const void* scale_host,
+                   const void* shift_host, const void* mask_cb8, float drop_scale, int per_image, void* dx_cb8,
+                   void* dw_host, void* dscale_host, void* dshift_host, int N, int C, int Z, int S, void* stream);
+
+/* dL/dx of Conv3d(k = 3x3x3 pad 1 (ksize 3) | 1x1x1 (ksize 1)): dy CB8 [N, Cout, Z, S, S] -> dx CB8 [N, Cin, Z, S, S];
+ * w [Cout][Cin][k^3] HOST as in the reference state_dict.  Runs on the forward MFMA conv kernel with re-packed weights. */
+int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx_cb8, int N, int Cin, int Cout, int Z, int S,
+                     int ksize, void* stream);
+
+/* dL/dw [Cout][Cin][k^3] and dL/dbias [Cout] (HOST outputs; db may be NULL) of the same convs. */
+int tm_op_conv_wgrad(const void* x_cb8, const void* dy_cb8, void* dw_host, void* db_host_or_null, int N, int Cin,
+                     int Cout, int Z, int S, int ksize, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,10 @@ SIGNATURES = {
     "tm_op_conv27_fused": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "tm_op_conv1_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4),
     "tm_op_conv1_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "tm_op_prep_train": (c_int, [c_void_p] * 5 + [c_float, c_int, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "tm_op_prep_bwd": (c_int, [c_void_p] * 6 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "tm_op_conv_dgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "tm_op_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "tm_op_window_attn": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "tm_op_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
 }

@@ -146,6 +146,11 @@ struct PrepLaunch {
   long raw_h_nstride = 0;
   int h_f16 = 0;                    // the 16-bit tensors (out_h, raw_h, mod_*_h, sources with src_h) are IEEE half instead of bf16
   int src_h = 0;                    // the SOURCES are 16-bit CB8 tensors (src[k].p reinterpreted; nstride in elements)
+  // training forward (nn.Dropout(p) of ResBlock.out_layers, model/MBAblocks.py:196-203) with a SUPPLIED keep mask:
+  // out = act(...) * drop_mask * drop_scale; drop_mask is an fp32 CB8 tensor of the output geometry (0 / 1) or null
+  const float* drop_mask = nullptr;
+  long drop_ns = 0;
+  float drop_scale = 1.f;
 };
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
 
@@ -217,6 +222,14 @@ hipError_t launch_sampler_step(const StepCoefs& c, const float* x_patches, const
                                int mode, hipStream_t s);
 hipError_t launch_pad_patchify(const float* img, float* patches, int b, int C, int P1, int P2,
                                int ps, float pad, hipStream_t s);
+
+// ---- training slice (tm_train.hip): backward of the prep chain, conv weight gradient, bias gradient ----
+hipError_t launch_prep_bwd(const float* x, long x_ns, const float* g, long g_ns, const float* mask, long mask_ns, float drop_scale,
+                           const float* w, const float* scale, const float* shift, long mod_stride, int per_image, float* dx,
+                           long dx_ns, float* dw, float* dscale, float* dshift, int N, int Cb, int C_real, int Z, int S,
+                           hipStream_t s);
+hipError_t launch_conv_wgrad(const TV& x, const TV& dy, float* dw, int Cin, int Cout, int taps, hipStream_t s);
+hipError_t launch_chan_sum(const TV& x, float* out, int C, hipStream_t s);
 
 // ---- tile I/O (tm_io.hip) --------------------------------------------------------------
 int io_fail(int code, const char* msg);     // sets the tm_last_error() text, returns code

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         // SiLU: exact expf / division where the result stays fp32; hardware exp2 / rcp (1 ulp) where it is rounded to a
         // 16-bit type anyway (the 16-bit modes: 8 or 11 significant bits survive)
         if (L.act) v = L.out_h ? v * __frcp_rn(1.0f + __expf(-v)) : silu_f(v);
+        if (L.drop_mask) v *= L.drop_mask[(long)n * L.drop_ns + (long)gb * oplane + oin + j] * L.drop_scale;
         o[j] += v;
       }
     }

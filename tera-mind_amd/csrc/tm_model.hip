@@ -1632,3 +1632,133 @@ extern "C" int tm_op_conv_direct(const void* x, const void* w_host, const void* 
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv_direct execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// training slice: forward with dropout + backward of one ResBlock's pieces
+// ------------------------------------------------------------------------------------------
+// host vector -> device copy living until `free_all`
+struct DevTmp {
+  std::vector<void*> ptrs;
+  float* up(const float* host, size_t n, size_t n_alloc = 0) {
+    float* d = nullptr;
+    if (n_alloc < n) n_alloc = n;
+    if (hipMalloc((void**)&d, n_alloc * sizeof(float)) != hipSuccess) return nullptr;
+    ptrs.push_back(d);
+    if (n_alloc > n && hipMemset(d, 0, n_alloc * sizeof(float)) != hipSuccess) return nullptr;
+    if (n && hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+  }
+  ~DevTmp() { for (void* p : ptrs) (void)hipFree(p); }
+};
+// per-channel vector [rows][C] -> [rows][Cb*8] zero padded (host)
+static std::vector<float> pad_rows(const float* v, int rows, int C, int Cp) {
+  std::vector<float> o((size_t)rows * Cp, 0.f);
+  for (int r = 0; r < rows; ++r) memcpy(o.data() + (size_t)r * Cp, v + (size_t)r * C, C * sizeof(float));
+  return o;
+}
+
+extern "C" int tm_op_prep_train(const void* x_cb8, const void* norm_w_host, const void* scale_host, const void* shift_host,
+                                const void* mask_cb8, float drop_scale, int per_image, void* y_cb8, int N, int C, int Z, int S,
+                                void* stream) {
+  if (!x_cb8 || !norm_w_host || !y_cb8 || per_image < 1) return fail(TM_ERR_ARG, "bad argument");
+  const int Cb = (C + 7) / 8, Cp = Cb * 8, nimg = (N + per_image - 1) / per_image;
+  DevTmp tmp;
+  const std::vector<float> wp = pad_rows((const float*)norm_w_host, 1, C, Cp);
+  const float* dw = tmp.up(wp.data(), Cp);
+  const float *dsc = nullptr, *dsh = nullptr;
+  if (scale_host) {
+    const std::vector<float> a = pad_rows((const float*)scale_host, nimg, C, Cp), b = pad_rows((const float*)shift_host, nimg, C, Cp);
+    dsc = tmp.up(a.data(), a.size()); dsh = tmp.up(b.data(), b.size());
+    if (!dsc || !dsh) return fail(TM_ERR_HIP, "device allocation failed");
+  }
+  if (!dw) return fail(TM_ERR_HIP, "device allocation failed");
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, C, Z, S, S), y = view_cb8(y_cb8, N, C, Z, S, S);
+  PrepLaunch P;
+  P.nsrc = 1;
+  P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+  P.N = N; P.Z = Z; P.S = S; P.norm_w = dw; P.inv_c = 1.0f / (float)C; P.act = 1; P.per_image = per_image;
+  if (dsc) { P.mod = MOD_IMAGE; P.mod_scale = dsc; P.mod_shift = dsh; P.mod_stride = Cp; }
+  if (mask_cb8) { P.drop_mask = (const float*)mask_cb8; P.drop_ns = x.nstride; P.drop_scale = drop_scale; }
+  P.out = y.p; P.out_nstride = y.nstride;
+  hipError_t e = launch_prep(P, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "prep (training forward): %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
+extern "C" int tm_op_prep_bwd(const void* x_cb8, const void* g_cb8, const void* norm_w_host, const void* scale_host,
+                              const void* shift_host, const void* mask_cb8, float drop_scale, int per_image, void* dx_cb8,
+                              void* dw_host, void* dscale_host, void* dshift_host, int N, int C, int Z, int S, void* stream) {
+  if (!x_cb8 || !g_cb8 || !norm_w_host || !dx_cb8 || !dw_host || per_image < 1) return fail(TM_ERR_ARG, "bad argument");
+  if (scale_host && (!shift_host || !dscale_host || !dshift_host)) return fail(TM_ERR_ARG, "scale without shift / gradient outputs");
+  const int Cb = (C + 7) / 8, Cp = Cb * 8, nimg = (N + per_image - 1) / per_image;
+  DevTmp tmp;
+  const std::vector<float> wp = pad_rows((const float*)norm_w_host, 1, C, Cp);
+  const float* dwt = tmp.up(wp.data(), Cp);
+  float* ddw = tmp.up(nullptr, 0, Cp);
+  const float *dsc = nullptr, *dsh = nullptr;
+  float *ddsc = nullptr, *ddsh = nullptr;
+  if (scale_host) {
+    const std::vector<float> a = pad_rows((const float*)scale_host, nimg, C, Cp), b = pad_rows((const float*)shift_host, nimg, C, Cp);
+    dsc = tmp.up(a.data(), a.size()); dsh = tmp.up(b.data(), b.size());
+    ddsc = tmp.up(nullptr, 0, (size_t)(nimg + 1) * Cp); ddsh = tmp.up(nullptr, 0, (size_t)(nimg + 1) * Cp);
+    if (!dsc || !dsh || !ddsc || !ddsh) return fail(TM_ERR_HIP, "device allocation failed");
+  }
+  if (!dwt || !ddw) return fail(TM_ERR_HIP, "device allocation failed");
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, C, Z, S, S);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = launch_prep_bwd(x.p, x.nstride, (const float*)g_cb8, x.nstride, (const float*)mask_cb8, x.nstride, drop_scale, dwt,
+                                 dsc, dsh, Cp, per_image, (float*)dx_cb8, x.nstride, ddw, ddsc, ddsh, N, Cb, C, Z, S, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "prep backward: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  std::vector<float> h(Cp);
+  HIP_TRY(hipMemcpy(h.data(), ddw, Cp * sizeof(float), hipMemcpyDeviceToHost));
+  memcpy(dw_host, h.data(), C * sizeof(float));
+  if (scale_host) {
+    std::vector<float> hs((size_t)nimg * Cp), hh((size_t)nimg * Cp);
+    HIP_TRY(hipMemcpy(hs.data(), ddsc, hs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hh.data(), ddsh, hh.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int r = 0; r < nimg; ++r) {
+      memcpy((float*)dscale_host + (size_t)r * C, hs.data() + (size_t)r * Cp, C * sizeof(float));
+      memcpy((float*)dshift_host + (size_t)r * C, hh.data() + (size_t)r * Cp, C * sizeof(float));
+    }
+  }
+  return TM_OK;
+}
+
+// dX of Conv3d(k = 3x3x3 pad 1 | 1x1x1), stride 1: the forward MFMA conv of dY with the kernel flipped in z, y, x and
+// cin <-> cout transposed (w_host [Cout][Cin][taps] as in the reference state_dict)
+extern "C" int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx_cb8, int N, int Cin, int Cout, int Z, int S,
+                                int ksize, void* stream) {
+  if (!dy_cb8 || !w_host || !dx_cb8 || (ksize != 1 && ksize != 3)) return fail(TM_ERR_ARG, "bad argument");
+  const int taps = ksize == 1 ? 1 : 27;
+  const float* w = (const float*)w_host;
+  std::vector<float> wt((size_t)Cin * Cout * taps);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < taps; ++t) wt[((size_t)ci * Cout + co) * taps + (taps - 1 - t)] = w[((size_t)co * Cin + ci) * taps + t];
+  std::vector<float> zb(Cin, 0.f);
+  return tm_op_conv_mfma(dy_cb8, wt.data(), zb.data(), dx_cb8, N, Cout, Cin, Z, S, ksize, ZM_PAD1, 0, 0, stream);
+}
+
+// dW [Cout][Cin][taps] and db [Cout] (HOST outputs) of the same convs from the forward input x and dY
+extern "C" int tm_op_conv_wgrad(const void* x_cb8, const void* dy_cb8, void* dw_host, void* db_host_or_null, int N, int Cin,
+                                int Cout, int Z, int S, int ksize, void* stream) {
+  if (!x_cb8 || !dy_cb8 || !dw_host || (ksize != 1 && ksize != 3)) return fail(TM_ERR_ARG, "bad argument");
+  if (ksize == 3 && Z != 2) return fail(TM_ERR_ARG, "3x3x3 weight gradient: Z must be 2 (the checkpoint model)");
+  const int taps = ksize == 1 ? 1 : 27;
+  hipStream_t st = (hipStream_t)stream;
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, Cin, Z, S, S), dy = view_cb8(const_cast<void*>(dy_cb8), N, Cout, Z, S, S);
+  DevTmp tmp;
+  const size_t nw = (size_t)Cout * Cin * taps;
+  float* ddw = tmp.up(nullptr, 0, nw);
+  float* ddb = tmp.up(nullptr, 0, (size_t)dy.Cb * 8);
+  if (!ddw || !ddb) return fail(TM_ERR_HIP, "device allocation failed");
+  hipError_t e = launch_conv_wgrad(x, dy, ddw, Cin, Cout, taps, st);
+  if (e == hipSuccess && db_host_or_null) e = launch_chan_sum(dy, ddb, Cout, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "conv wgrad: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  HIP_TRY(hipMemcpy(dw_host, ddw, nw * sizeof(float), hipMemcpyDeviceToHost));
+  if (db_host_or_null) HIP_TRY(hipMemcpy(db_host_or_null, ddb, Cout * sizeof(float), hipMemcpyDeviceToHost));
+  return TM_OK;
+}

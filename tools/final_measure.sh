@@ -1,30 +1,40 @@
 #!/bin/bash
 # Round-end measurement refresh on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1200 -- 'bash tools/final_measure.sh'
-# Writes everything under gpurun_out/final/; tools/rocpd_stats.py and tools/pmc_summary.py turn the
-# outputs into the summaries committed under profiles/ (tools/final_collect.sh).
+# Writes everything under gpurun_out/final/; tools/final_collect.sh turns it into the summaries committed under profiles/.
+# One step per line; a step that is killed / times out ends the script (no GPU step is started behind a hung one).
 set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/final
-mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-
-timeout -k 10 300 python3 bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err &&
-timeout -k 10 200 python3 bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err &&
-timeout -k 10 200 python3 bench.py --tile --no-cpu-baseline > $OUT/bench_tile_f32.json 2> $OUT/bench_tile_f32.err &&
-timeout -k 10 200 python3 bench.py --tile --dtype bf16 --no-cpu-baseline > $OUT/bench_tile_bf16.json 2> $OUT/bench_tile_bf16.err &&
-echo "bench done" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_f32 -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_f32_under_rocprof.json 2> $OUT/prof_f32.err &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_bf16 -o bench -- python3 bench.py --dtype bf16 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_bf16_under_rocprof.json 2> $OUT/prof_bf16.err &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_tile_f32 -o bench -- python3 bench.py --tile --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/prof_tile_f32.err &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_tile_bf16 -o bench -- python3 bench.py --tile --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/prof_tile_bf16.err &&
-echo "trace done" || exit 1
+rm -rf "$OUT"; mkdir -p "$OUT"
+run() {   # name timeout command...
+  local name=$1 tmo=$2; shift 2
+  timeout -k 10 "$tmo" "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+  local rc=$?
+  echo "== $name rc=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 143 ]; then echo "killed: stopping"; exit $rc; fi
+}
+run bench_f32 400 python3 bench.py
+run bench_bf16 200 python3 bench.py --dtype bf16 --no-cpu-baseline --no-sweep
+run bench_f16 200 python3 bench.py --dtype f16 --no-cpu-baseline --no-sweep
+run bench_tile_f32 200 python3 bench.py --tile --no-cpu-baseline --no-sweep --steps 5
+run bench_tile_bf16 200 python3 bench.py --tile --dtype bf16 --no-cpu-baseline --no-sweep --steps 5
+run bench_tile_f16 200 python3 bench.py --tile --dtype f16 --no-cpu-baseline --no-sweep --steps 5
+run bench_sweep_bf16_b7 300 python3 bench.py --sweep --sweep-hnm 2 --sweep-wnm 14 --sweep-batch-tiles 7 --steps 2 --warmup 1 --no-cpu-baseline
+echo "bench done"
+# kernel traces (the program itself after `--`: no env / shell hop under the profiler)
+for W in "f32:" "bf16:--dtype bf16" "tile_f32:--tile" "tile_bf16:--tile --dtype bf16"; do
+  TAGW=${W%%:*}; FL=${W#*:}
+  run trace_$TAGW 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAGW" -o bench -- python3 bench.py $FL --steps 3 --warmup 1 --no-cpu-baseline --no-sweep
+done
+echo "trace done"
 # PMC: one counter set per pass (gfx950 slot limits; never together with the trace domains)
 for W in "f32:" "bf16:--dtype bf16" "tile_f32:--tile" "tile_bf16:--tile --dtype bf16"; do
   TAGW=${W%%:*}; FL=${W#*:}
-  for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${TAGW}_$C -o pmc -- python3 bench.py $FL --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_${TAGW}_$C.err || exit 1
-  done
+  run pmc_${TAGW}_FETCH 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_${TAGW}_FETCH_SIZE" -o pmc -- python3 bench.py $FL --steps 1 --warmup 1 --no-cpu-baseline --no-sweep
+  run pmc_${TAGW}_WRITE 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_${TAGW}_WRITE_SIZE" -o pmc -- python3 bench.py $FL --steps 1 --warmup 1 --no-cpu-baseline --no-sweep
+  run pmc_${TAGW}_SQ 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_${TAGW}_SQ" -o pmc -- python3 bench.py $FL --steps 1 --warmup 1 --no-cpu-baseline --no-sweep
   echo "pmc $TAGW done"
 done
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_f32_SQ -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_f32_SQ.err || exit 1
-echo "pmc SQ done"
+python3 tools/pmc_stamp.py > "$OUT/src_sha.txt"
+echo "all done"

@@ -15,6 +15,8 @@ import sys
 import tempfile
 import time
 
+_T_START = time.monotonic()
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -52,38 +54,62 @@ def worker(args):
     cfg = PathConfig(compute_dtype=args.dtype)
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
     T = args.tot_epoch
+    holder = {}
+    if args.deadline_s and world > 1:
+        raise SystemExit("--deadline_s is for single-GPU runs")
     if args.gene_dir:
         genes = GeneTileDir(args.gene_dir, cfg, dev, total_slc=50, keep_resident=True)
     else:
         genes = device_gene_provider(cfg, dev)
 
+    class Deadline(Exception):
+        pass
+
     def on_step(sw, s):
         if rank == 0:
-            print(f"[run_roi] step {sw.epoch}/{T}: {s:.2f} s", file=sys.stderr, flush=True)
+            print(f"[run_roi] step {sw.epoch}/{T}: {s:.2f} s  (process age {time.monotonic() - _T_START:.0f} s)", file=sys.stderr, flush=True)
+        # the GPU runner ends a command at a fixed wall-clock limit: never start a step that cannot finish inside it
+        if args.deadline_s and sw.epoch < T and time.monotonic() - _T_START + 1.03 * s > args.deadline_s:
+            raise Deadline()
 
-    t_load = time.perf_counter()
-    res = launch.run_sweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, hnm=args.hnm, wnm=args.wnm, total_epochs=T,
-                           steps=T, warmup=0, device=dev, batch_tiles=args.batch_tiles, init=args.init, state=args.state,
-                           on_step=on_step)
+    steps_done = T
+    try:
+        res = launch.run_sweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, hnm=args.hnm, wnm=args.wnm, total_epochs=T,
+                               steps=T, warmup=0, device=dev, batch_tiles=args.batch_tiles, init=args.init, state=args.state,
+                               on_step=on_step, holder=holder)
+    except Deadline:
+        # single-rank runs only (a rank that stops alone would leave its neighbours in the strip exchange)
+        sw = holder["sweep"]
+        torch.cuda.synchronize()
+        steps_done = sw.epoch
+        res = {"sweep": sw, "dt": sum(holder["step_s"]), "step_s": holder["step_s"], "exchange_ms_per_step": 0.0}
     sw, sweep_s, per_step = res["sweep"], res["dt"], res["step_s"]
     st = sw.local_state()
     out_dir = args.out_dir or tempfile.mkdtemp(prefix="roi_")
     t2 = time.perf_counter()
-    d = sw.save_step(os.path.join(out_dir, "timestep"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    io_save = time.perf_counter() - t2
+    io_save, d = 0.0, None
+    if not args.no_tile_files:
+        d = sw.save_step(os.path.join(out_dir, "timestep"))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        io_save = time.perf_counter() - t2
     if rank == 0:
         t3 = time.perf_counter()
-        mosaic = stitch.stitch_dir(d, 256, 256, args.hnm, args.wnm, 50, slices=[0, 1, 48, 49])
+        same = None
+        if d is not None:
+            mosaic = stitch.stitch_dir(d, 256, 256, args.hnm, args.wnm, 50, slices=[0, 1, 48, 49])
+            if world == 1:
+                same = bool(np.array_equal(mosaic, stitch.stitch_state(st, 50, [0, 1, 48, 49]).cpu().numpy()))
+        else:                                   # mosaic straight from the resident canvas (infer_brn.py:57-105 on device)
+            mosaic = stitch.stitch_state(st, 50, [0, 1, 48, 49]).cpu().numpy()
         stitch.save_slices(mosaic, os.path.join(out_dir, "gen"), names=[0, 1, 48, 49])
         io_s = io_save + time.perf_counter() - t3
-        same = None
-        if world == 1:
-            same = bool(np.array_equal(mosaic, stitch.stitch_state(st, 50, [0, 1, 48, 49]).cpu().numpy()))
         tiles = args.hnm * args.wnm
-        print(json.dumps({"what": "full ROI sweep, measured", "dtype": args.dtype, "state": args.state, "tiles": tiles, "T": T,
+        T = steps_done
+        print(json.dumps({"what": "full ROI sweep, measured", "steps_requested": args.tot_epoch, "steps_measured": steps_done,
+                          "step_s": [round(v, 2) for v in per_step], "process_age_s": round(time.monotonic() - _T_START, 1),
+                          "tile_files_written": d is not None, "dtype": args.dtype, "state": args.state, "tiles": tiles, "T": T,
                           "n_gpus": world, "genes": "on-disk COO .npz via GeneTileDir + tm_gene_tile_dense" if args.gene_dir else "synthetic, device resident",
                           "init": args.init, "batch_tiles": args.batch_tiles,
                           "sweep_s": round(sweep_s, 2), "sweep_min": round(sweep_s / 60, 2), "s_per_tile_step": round(sweep_s * world / (tiles * T), 4),
@@ -113,6 +139,9 @@ def main():
     ap.add_argument("--gene_dir", default=None)
     ap.add_argument("--make_genes", type=int, default=0, help="write synthetic COO gene tiles with this many entries each into --gene_dir first")
     ap.add_argument("--out_dir", default=None)
+    ap.add_argument("--deadline_s", type=float, default=0.0,
+                    help="single GPU: do not start a diffusion step that would end later than this many seconds after process start")
+    ap.add_argument("--no_tile_files", action="store_true", help="skip save_step / stitch_dir; stitch slice images from the resident canvas")
     args = ap.parse_args()
     from teramind_amd import launch
     if args.gene_dir and args.make_genes and not launch.launched_as_rank():
