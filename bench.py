@@ -164,6 +164,15 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     model.profile(False)
     st = res["sweep"].local_state()
     assert torch.isfinite(st.float()).all(), "non-finite sweep state"
+    # partition-independent digest of the whole ROI state: exact integer sums over the fp16 bit patterns of every rank's rows
+    bits = st.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+    dig = torch.stack([bits.sum(), (bits * bits).sum(), torch.tensor(bits.numel(), device=bits.device)])
+    if world > 1:
+        import torch.distributed as dist
+        dh = dig if dist.get_backend() == "nccl" else dig.cpu()
+        dist.all_reduce(dh, op=dist.ReduceOp.SUM)
+        dig = dh
+    digest = [int(v) for v in dig.cpu()]
     tiles = args.sweep_hnm * args.sweep_wnm
     value = 400.0 * tiles * steps / res["dt"]
     out = {"value": round(value, 3), "unit": "interior patch-steps/s", "scaling": "strong", "dtype": args.sweep_dtype,
@@ -176,7 +185,7 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
            "exchange_ms_per_step": round(res["exchange_ms_per_step"], 3),
            "exchange_bytes_per_step_per_rank": res["exchange_bytes_per_step"],
            "weights_broadcast_bytes": int(model.arena().numel()) if world > 1 else 0,
-           "rows_rank0": list(res["rows"])}
+           "rows_rank0": list(res["rows"]), "state_digest": digest}
     return out, prof, res["dt"], value
 
 
@@ -193,9 +202,13 @@ def worker(args):
     rank, local_rank, world = launch.dist_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    if args.rehearse:
+        # every rank on cuda:0 over gloo: rehearses the multi-process path (launcher, partition, arena broadcast, strip
+        # exchange, reductions) on a one-GPU box; the numbers it prints are not a measurement
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    launch.init_distributed("nccl", dev)
+    launch.init_distributed("gloo" if args.rehearse else "nccl", dev)
 
     B_IMAGES, P, gen = (25, 4, "ddim") if args.tile else (32, 1, "ddpm")
     cfg = PathConfig(gen_type=gen, batch_size=B_IMAGES, compute_dtype=args.dtype)
@@ -206,8 +219,7 @@ def worker(args):
         log("packing + uploading weights")
         model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
         log("model ready")
-        if world > 1:      # replaces DDP's construction-time parameter broadcast (test_brn.py:149)
-            dist.broadcast(model.arena(), src=0)
+        launch.broadcast_arena(model)      # replaces DDP's construction-time parameter broadcast (test_brn.py:149)
         smp = SpacedDiffusionBeatGans(T_STEPS, gen)
 
         b, C, ps = B_IMAGES, cfg.in_channels, cfg.patch_size
@@ -256,9 +268,7 @@ def worker(args):
         log(f"timed region done: {dt:.3f} s for {args.steps} steps")
         if world > 1:
             dist.barrier()
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        dt = launch.reduce_max([dt], dev)[0]
         assert torch.isfinite(state).all(), "non-finite state"
         del model
         if rank == 0:
@@ -322,6 +332,8 @@ def main():
     ap.add_argument("--sweep-steps", type=int, default=2, help="timed diffusion steps of the appended sweep (1 warm-up step)")
     ap.add_argument("--sweep-dtype", choices=["bf16", "f16", "f32"], default="bf16")
     ap.add_argument("--sweep-batch-tiles", type=int, default=1)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (checks the plumbing, measures nothing)")
     args = ap.parse_args()
     from teramind_amd import launch          # imports neither torch nor the HIP library
     if args.gpus > 1 and not launch.launched_as_rank():

@@ -103,6 +103,34 @@ def init_distributed(backend: str, device=None):
     return rank, local_rank, world
 
 
+def broadcast_arena(model) -> int:
+    """Rank 0's packed weight arena to every rank: ONE collective in place of DDP's construction-time parameter broadcast
+    (test_brn.py:149).  RCCL on the device; with gloo (CPU tests, rehearsals that share one GPU) staged through host memory.
+    Returns the number of bytes broadcast (0 when there is no process group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not hasattr(model, "arena"):
+        return 0
+    a = model.arena()
+    if dist.get_backend() == "gloo" and a.is_cuda:
+        h = a.cpu()
+        dist.broadcast(h, src=0)
+        a.copy_(h)
+    else:
+        dist.broadcast(a, src=0)
+    return int(a.numel())
+
+
+def reduce_max(values, device):
+    """MAX over ranks of a few host floats (timings); returns them unchanged without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
 def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: int, total_epochs: int, steps: int,
               warmup: int = 0, device="cpu", total_slc: int = 50, hst: int = 256, wst: int = 256, batch_tiles: int = 1,
               init: str = "device", state: str = "fp16", broadcast_weights: bool = True, time_exchange: bool = True,
@@ -122,15 +150,8 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
         rank, world = 0, 1
     dev = torch.device(device)
     cuda = dev.type == "cuda"
-    if dist_on and broadcast_weights and model is not None and hasattr(model, "arena"):
-        # replaces DDP's construction-time parameter broadcast (test_brn.py:149): one collective over the packed arena
-        a = model.arena()
-        if dist.get_backend() == "gloo" and a.is_cuda:
-            h = a.cpu()
-            dist.broadcast(h, src=0)
-            a.copy_(h)
-        else:
-            dist.broadcast(a, src=0)
+    if dist_on and broadcast_weights and model is not None:
+        broadcast_arena(model)
     sw = brain.TileSweep(conf, sampler, model, gene_provider, hst=hst, wst=wst, hnm=hnm, wnm=wnm, total_epochs=total_epochs,
                          total_slc=total_slc, device=dev, rank=rank, world=world, batch_tiles=batch_tiles, init=init, state=state)
     sw.time_exchange = time_exchange
@@ -170,11 +191,7 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
     fence()
     dt = time.perf_counter() - t0
     exch_ms = 1e3 * sw.exchange_s / max(1, steps)
-    if dist_on:
-        red_dev = dev if dist.get_backend() == "nccl" else "cpu"
-        tt = torch.tensor([dt, exch_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, exch_ms = float(tt[0]), float(tt[1])
+    dt, exch_ms = reduce_max([dt, exch_ms], dev)
     return {"sweep": sw, "dt": dt, "step_s": step_s, "exchange_ms_per_step": exch_ms,
             "exchange_bytes_per_step": sw.exchange_bytes // max(1, steps), "world": dist.get_world_size() if dist_on else 1,
             "backend": dist.get_backend() if dist_on else "none", "rows": (sw.r0, sw.r1)}
