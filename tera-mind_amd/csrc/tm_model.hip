@@ -841,12 +841,16 @@ static TV res_block_h16(Ctx& cx, const ResW& w, const std::vector<Src>& src, int
   if (fuse_mid) {
     run_conv_h(cx, Ah, w.c1h, w.c1, geom, nullptr, w.cin, &A2h, &w, per_image);
   } else {
-    TV H1 = cx.tensor(N, w.cout, Z, S_out);                  // fp32: the norm statistics are taken on the unrounded conv output
-    run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin);
+    // Cout > 128 (several cout tiles per voxel): the conv output goes through a 16-bit tensor like every other conv
+    // output of the 16-bit modes -- under the reference's autocast in_layers' Conv3d returns fp16 and out_layers'
+    // LlamaRMSNorm takes its statistics from those half values (MBAblocks.py:21-43 casts the half input up)
+    TV H1 = cx.tensor_s(N, w.cout, Z, S_out);
+    run_conv_h(cx, Ah, w.c1h, w.c1, H1, nullptr, w.cin, nullptr, nullptr, 1, true);
     if (!cx.dry) {
       PrepLaunch P;
       P.nsrc = 1;
       P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
+      P.src_h = 1;
       P.N = N; P.Z = Z; P.S = S_out;
       P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
       P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
