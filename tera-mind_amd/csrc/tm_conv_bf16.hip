@@ -287,6 +287,9 @@ __device__ __forceinline__ void col_to_vox(int T, int i32, int& ps, int& r, int&
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+#ifndef TM_ABL
+#define TM_ABL 0      // diagnostic builds: 1 = no stage barrier, 8 = barrier without waiting for the LDS-DMAs, 2 = no fragment ds_reads after a stage's first tap, 4 = no LDS-DMA after stage 0
+#endif
 #ifdef TM_STAMPS
 // Diagnostic build only (make diag -> libteramind_hip_diag.so, tools/conv27_stamps.py): wave 0 of every workgroup records
 // s_memtime at kernel entry, main-loop entry, main-loop exit and kernel exit into a buffer of its own.
@@ -418,38 +421,64 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   // groups of taps 0 .. 3: a wave's VMEM issue overlaps its own and its SIMD partner's MFMAs, and the last piece still
   // has five taps (~2.5k cycles) to land before the barrier.
   constexpr int PPT = (NP + 3) / 4;
+  constexpr int PPH = (NP + 1) / 2;                    // pieces per tap when a wave issues its share behind two taps
 
   const int NH = npl * ah.Cbp;
 #pragma unroll
   for (int p = 0; p < NP; ++p) issue_piece(0, p);
   __syncthreads();
   TM_STAMP(1);
+  // Fragment registers: THREE sets.  Tap 0 of a stage uses set 2, taps t >= 1 use set (t - 1) & 1; tap t + 1's ds_reads
+  // are issued before tap t's MFMAs.  The stage barrier sits in FRONT of tap 8's MFMAs, not behind them: once every wave
+  // has its tap-8 fragments in registers the buffer is dead, so the waves synchronise there, request the next stage's
+  // tap-0 fragments (set 2) from the other buffer right away and only then issue tap 8's eight MFMAs -- the LDS round
+  // trip of a new stage's first reads (all eight waves hit the LDS at once) is covered by matrix work instead of
+  // leaving the four matrix pipes idle behind every barrier.
+  bf16x8 wf[3][2], xf[3][4];
+  {
+    const u32x4* buf0 = lds16;
+    wf[2][0] = __builtin_bit_cast(bf16x8, buf0[wb]);
+    wf[2][1] = __builtin_bit_cast(bf16x8, buf0[64 + wb]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xf[2][mt] = __builtin_bit_cast(bf16x8, buf0[xb[mt]]);
+  }
   for (int hs = 0; hs < NH; ++hs) {
     const bool more = hs + 1 < NH;
     const u32x4* buf = lds16 + (hs & 1) * G::BUF16;
-    // fragment registers are double-buffered by hand: tap t+1's ds_reads are issued before tap t's MFMAs
-    bf16x8 wf[2][2], xf[2][4];
-    wf[0][0] = __builtin_bit_cast(bf16x8, buf[wb]);
-    wf[0][1] = __builtin_bit_cast(bf16x8, buf[64 + wb]);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) xf[0][mt] = __builtin_bit_cast(bf16x8, buf[xb[mt]]);
+    const u32x4* nbuf = lds16 + ((hs + 1) & 1) * G::BUF16;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int cur = tap & 1, nxt = cur ^ 1;
+      const int cur = tap == 0 ? 2 : ((tap - 1) & 1);
+      const int nxt = tap & 1;                             // set of tap + 1 (taps 1 .. 8)
       // This tap's fragments were requested one tap ago, behind eight MFMAs: they have long landed.  Saying so HERE, before
       // the next tap's reads are issued, keeps hipcc from waiting lgkmcnt(0) after them (it does not emit a counted
       // lgkmcnt(6) in this loop), which would expose a full LDS round trip in front of every second MFMA group.
-      if (tap > 0) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0) only (vmcnt / expcnt fields = no wait)
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) only (vmcnt / expcnt fields = no wait)
+      __builtin_amdgcn_sched_barrier(0);
       if (tap < 8) {
         const int t1 = tap + 1;
         const int xd = (t1 / 3) * G::HCP + (t1 % 3);
-        wf[nxt][0] = __builtin_bit_cast(bf16x8, buf[t1 * TN * 2 + wb]);
-        wf[nxt][1] = __builtin_bit_cast(bf16x8, buf[t1 * TN * 2 + 64 + wb]);
+        if (!(TM_ABL & 2)) {
+          wf[nxt][0] = __builtin_bit_cast(bf16x8, buf[t1 * TN * 2 + wb]);
+          wf[nxt][1] = __builtin_bit_cast(bf16x8, buf[t1 * TN * 2 + 64 + wb]);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xf[nxt][mt] = __builtin_bit_cast(bf16x8, buf[xb[mt] + xd]);
+          for (int mt = 0; mt < 4; ++mt) xf[nxt][mt] = __builtin_bit_cast(bf16x8, buf[xb[mt] + xd]);
+        } else {
+          wf[nxt][0] = wf[2][0]; wf[nxt][1] = wf[2][1];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) xf[nxt][mt] = xf[2][mt];
+        }
+      } else {
+        // every fragment of this buffer is in registers (the wait above); this wave's share of the next stage has landed
+        // once its LDS-DMAs have drained (the vmcnt(0) of __syncthreads); behind the barrier everyone's has
+        if (TM_ABL & 8) __builtin_amdgcn_s_barrier();          // diagnostic: barrier WITHOUT the vmcnt(0) drain of the LDS-DMAs
+        else if (!(TM_ABL & 1)) __syncthreads();
+        if (more) {
+          wf[2][0] = __builtin_bit_cast(bf16x8, nbuf[wb]);
+          wf[2][1] = __builtin_bit_cast(bf16x8, nbuf[64 + wb]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) xf[2][mt] = __builtin_bit_cast(bf16x8, nbuf[xb[mt]]);
+        }
       }
       // keep tap t+1's ds_reads above tap t's MFMAs (hipcc otherwise sinks them to just before their use and
       // every 8-MFMA group eats a full LDS round trip)
@@ -460,13 +489,24 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
         for (int mt = 0; mt < 4; ++mt)
           acc[ct][mt] = TM_MFMA16(wf[cur][ct], xf[cur][mt], acc[ct][mt]);
       __builtin_amdgcn_sched_barrier(0);
-      if (more && tap < 4) {
+      if (more && tap < 4 && !(TM_ABL & 4)) {
+        if (NWV == 8) {
+          // Waves w and w + 4 share a SIMD and leave every barrier in lockstep.  An LDS-DMA instruction blocks its wave's
+          // issue for 100-200 cycles; issued by both partners behind the same MFMA groups, those blocks coincide and the
+          // matrix pipe idles for all of them (tools/conv27_stamps.py ablation: 6250 cycles per stage with, 4850 without
+          // the DMAs, 4608 ideal).  So the halves take turns: waves 0-3 issue their pieces behind taps 0 and 1, waves 4-7
+          // behind taps 2 and 3 -- a wave's DMA issue then runs under its partner's MFMAs.
+          if ((tap >> 1) == (wv >> 2)) {
 #pragma unroll
-        for (int p = tap * PPT; p < (tap + 1) * PPT && p < NP; ++p) issue_piece(hs + 1, p);
+            for (int p = (tap & 1) * PPH; p < ((tap & 1) + 1) * PPH && p < NP; ++p) issue_piece(hs + 1, p);
+          }
+        } else {
+#pragma unroll
+          for (int p = tap * PPT; p < (tap + 1) * PPT && p < NP; ++p) issue_piece(hs + 1, p);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();          // drains this wave's LDS-DMA (vmcnt) and fences the buffer swap
   }
   TM_STAMP(2);
   if (FUSE) fused_norm_epilogue<G::WNW>(ah, acc, wn, wm, i32, h, on, ooff, (float*)lds16);

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TM_LIB_PATH"] = os.path.join(ROOT, "tera-mind_amd", "csrc", "libteramind_hip_diag.so")
+os.environ["TM_LIB_PATH"] = os.path.join(ROOT, "tera-mind_amd", "csrc", "libteramind_hip_diag%s.so" % os.environ.get("TM_DIAG_ABL", ""))
 
 
 def main():
