@@ -247,6 +247,20 @@ int tm_op_conv1_concat(const void* const* x_cb8, const int* cin, const int* coll
                        const void* bias_host, void* y_cb8, int N, int Cout, int Z, int S, int p1, int p2,
                        int dtype, int waves, void* stream);
 
+/* The block-input pass of the 16-bit modes on its own: th.cat of nsrc (1..3) sources (model/unet_ours.py:384,418) with
+ * to_collage (:325-341) where collage[i] != 0, optional nearest x2 (Upsample, model/blocks.py:362-371; up2 != 0: sources at
+ * S/2), LlamaRMSNorm over the real channel count c_real (model/MBAblocks.py:21-43; norm_w_dev: device fp32 [padded C], or
+ * null), modulation (mod 0 none; 1 per image: device fp32 scale / shift rows [b][mod_stride], image = n / per_image,
+ * apply_conditions :356-367; 2 per voxel: 16-bit CB8 scale / shift tensors of the output geometry with patch stride
+ * mod_stride elements, modulate :608-614), SiLU (act != 0).  Sources and outputs are 16-bit CB8 DEVICE tensors (dtype
+ * TM_DTYPE_BF16 / TM_DTYPE_F16); out_h16 has ceil(Cb / 2) * 2 channel blocks (pad blocks zero), raw_h16 (optional) receives
+ * the gathered, un-normalised input.  variant: 0 = the form the model picks, 1 = prep_kernel, 2 / 3 = prep_h16_kernel with one
+ * wave / four waves per 64 voxels.  iters >= 1 launches; elapsed_ms (host, optional): mean time of launches 2..iters. */
+int tm_op_prep_h16(const void* const* src_h16, const int* src_c, const int* collage, int nsrc, int N, int Z, int S,
+                   int p1, int p2, int up2, const void* norm_w_dev, int c_real, int mod, const void* mod_scale,
+                   const void* mod_shift, long mod_stride, int per_image, int act, int dtype, int variant,
+                   void* out_h16, void* raw_h16, int iters, float* elapsed_ms, void* stream);
+
 /* Windowed gene-patch cross attention core (model/MBAblocks.py:551-601 between the q/k/v Linears and proj):
  * q, k, v fp32 CB8 [N, C, Z, S, S]; qw, kw: device fp32 [C] (q_norm / k_norm weights).
  * dtype TM_DTYPE_F32: fp32 MFMA kernels, out = fp32 CB8.  TM_DTYPE_BF16: inputs are rounded to bf16 first (what the

@@ -69,6 +69,8 @@ SIGNATURES = {
     "tm_op_conv27_fused": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "tm_op_conv1_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4),
     "tm_op_conv1_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "tm_op_prep_h16": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_int, c_int, c_void_p, c_void_p, C.c_long] +
+                       [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "tm_op_prep_train": (c_int, [c_void_p] * 5 + [c_float, c_int, c_void_p] + [c_int] * 4 + [c_void_p]),
     "tm_op_prep_bwd": (c_int, [c_void_p] * 6 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "tm_op_conv_dgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

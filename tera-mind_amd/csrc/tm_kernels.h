@@ -153,6 +153,9 @@ struct PrepLaunch {
   float drop_scale = 1.f;
 };
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s);
+// test / measurement knob (tm_op_prep_h16): 0 automatic, 1 prep_kernel, 2 / 3 the two forms of prep_h16_kernel; process-wide,
+// set and reset around the op's own launches only
+void set_prep_variant(int v);
 
 // ---- generic direct conv (VALU) with strided accessors --------------------------------
 struct Acc5 {                        // address = n*sN + (c/8)*sCb + (c%8)*sC8 + z*sZ + y*sY + x*sX

@@ -674,7 +674,243 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// prep_h16_kernel: the same operation for the 16-bit activation stream (16-bit CB8 sources -> 16-bit CB8 output, resample
+// SAME / UP2), the form every block-input pass of the 16-bit modes takes.  HBM-bound byte work: 2 B read + 2 B written per
+// element (+ 4 B for a per-voxel modulation).  Differences from prep_kernel that matter for the memory system:
+//   * a lane keeps its voxel's channel blocks PACKED (4 VGPRs per 8 channels), so up to NB blocks per wave stay resident
+//     between the sum-of-squares pass and the apply pass for every channel count of the model family (<= 1280 channels):
+//     each source byte is read once;
+//   * all of a lane's loads are issued before the first use (NB 16-byte loads in flight per lane);
+//   * WS = 1: a wave owns 64 voxels and ALL their channel blocks -- no LDS, no barrier, 256 voxels per workgroup (the fine
+//     levels, where the old 64-voxel workgroups lived for a few hundred cycles each);
+//     WS = 4: the four waves split the channel blocks of 64 voxels and combine their sums of squares through LDS (coarse
+//     levels: few voxels, many channels).
+// ------------------------------------------------------------------------------------------
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+
+template <bool F16>
+__device__ __forceinline__ void unpack8(const pu32x4& v, float (&f)[8]) {
+  if (F16) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const h2 h = __builtin_bit_cast(h2, (unsigned int)v[j]);
+      f[2 * j] = (float)h[0]; f[2 * j + 1] = (float)h[1];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int w = v[j];
+      f[2 * j] = __uint_as_float(w << 16); f[2 * j + 1] = __uint_as_float(w & 0xffff0000u);
+    }
+  }
+}
+template <bool F16>
+__device__ __forceinline__ pu32x4 pack8(const float (&f)[8]) {
+  pu32x4 r;
+  if (F16) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h2 h; h[0] = (_Float16)f[2 * j]; h[1] = (_Float16)f[2 * j + 1]; r[j] = __builtin_bit_cast(unsigned int, h); }
+  } else {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b2 h; h[0] = (__bf16)f[2 * j]; h[1] = (__bf16)f[2 * j + 1]; r[j] = __builtin_bit_cast(unsigned int, h); }
+  }
+  return r;
+}
+
+template <int WS, int NB, bool F16>
+__global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
+  const PrepLaunch& L = pa.L;
+  __shared__ float red[WS == 4 ? 4 : 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int S = L.S, Z = L.Z;
+  const int vpn = Z * S * S;
+  const long vidx = (WS == 4 ? (long)blockIdx.x * 64 : ((long)blockIdx.x * 4 + wv) * 64) + lane;
+  const bool valid = vidx < (long)vpn * L.N;
+  int n = 0, z = 0, y = 0, x = 0;
+  if (valid) {
+    n = (int)(vidx / vpn);
+    int rem = (int)(vidx - (long)n * vpn);
+    z = rem / (S * S); rem -= z * S * S;
+    y = rem / S; x = rem - y * S;
+  }
+  const int Ss = L.resample == RS_UP2 ? S / 2 : S;
+  const long splane = (long)Z * Ss * Ss * 8;               // elements per channel block of a source patch
+  long soff[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    soff[k] = 0;
+    if (k >= L.nsrc) continue;
+    int ns = n, ys = y, xs = x;
+    if (L.src[k].collage) {
+      const int q1 = L.p1 - 1, q2 = L.p2 - 1;
+      const int bi = n / (q1 * q2);
+      const int q = n - bi * q1 * q2;
+      int i = q / q2, j = q - i * q2;
+      ys = y + S / 2; if (ys >= S) { ys -= S; i += 1; }
+      xs = x + S / 2; if (xs >= S) { xs -= S; j += 1; }
+      ns = bi * L.p1 * L.p2 + i * L.p2 + j;
+    }
+    if (L.resample == RS_UP2) { ys = y >> 1; xs = x >> 1; }
+    soff[k] = (long)ns * L.src[k].nstride + ((long)(z * Ss + ys) * Ss + xs) * 8;
+  }
+  const int cb0 = L.src[0].Cb, cb01 = cb0 + ((L.nsrc > 1) ? L.src[1].Cb : 0);
+  const int cbtot = cb01 + ((L.nsrc > 2) ? L.src[2].Cb : 0);
+  const int g0 = WS == 4 ? wv : 0;                          // this wave's virtual blocks: g0, g0 + WS, ...
+  pu32x4 c[NB];
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int gb = g0 + WS * i;
+      if (gb < cbtot) {
+        const int k = (gb >= cb0) + (gb >= cb01);              // wave-uniform
+        const int cb = gb - (k == 0 ? 0 : (k == 1 ? cb0 : cb01));
+        const uint16_t* sp = (const uint16_t*)(k == 0 ? L.src[0].p : (k == 1 ? L.src[1].p : L.src[2].p));
+        const long so = k == 0 ? soff[0] : (k == 1 ? soff[1] : soff[2]);
+        c[i] = *(const pu32x4*)(sp + so + (long)cb * splane);
+      }
+    }
+  }
+  float rstd = 1.f;
+  if (L.norm_w) {
+    // Both forms add in ONE order -- four partial sums over the blocks gb = r, r + 4, r + 8, ... (r = 0..3), then
+    // p0 + p1 + p2 + p3 -- so that the form (which depends on the size of the call) never changes a result bit: a patch
+    // computed inside a large batch equals the same patch computed alone.
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (g0 + WS * i < cbtot) {
+          float f[8];
+          unpack8<F16>(c[i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ps[WS == 4 ? 0 : (i & 3)] += f[j] * f[j];
+        }
+      }
+    }
+    float ssq;
+    if (WS == 4) {
+      red[wv][lane] = ps[0];
+      __syncthreads();
+      ssq = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    } else {
+      ssq = ps[0] + ps[1] + ps[2] + ps[3];
+    }
+    rstd = 1.0f / sqrtf(ssq * L.inv_c + TM_EPS);
+  }
+  if (!valid) return;
+  // the apply pass unpacks the resident blocks again: without this the compiler keeps the sum-of-squares pass's unpacked
+  // floats alive instead (8 VGPRs per block on top of the 4 packed ones)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(c[i]));
+  const long oplane = (long)vpn * 8;
+  const long oin = ((long)(z * S + y) * S + x) * 8;
+  const int img = n / L.per_image;
+  uint16_t* const outp = L.out_h + (long)n * L.out_h_nstride + oin;
+  uint16_t* const rawp = L.raw_h ? L.raw_h + (long)n * L.raw_h_nstride + oin : nullptr;
+  const long mo = (long)n * L.mod_stride + oin;
+  constexpr int CH = 4;                                      // blocks per chunk: their modulation loads are issued together
+#pragma unroll
+  for (int i0 = 0; i0 < NB; i0 += CH) {
+    pu32x4 msc[CH], msh[CH];
+    if (L.mod == MOD_VOXEL) {
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii) {
+        const int gb = g0 + WS * (i0 + ii);
+        if (i0 + ii < NB && gb < cbtot) {
+          msc[ii] = *(const pu32x4*)(L.mod_scale_h + mo + (long)gb * oplane);
+          msh[ii] = *(const pu32x4*)(L.mod_shift_h + mo + (long)gb * oplane);
+        }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+      const int i = i0 + ii;
+      const int gb = g0 + WS * i;
+      if (i < NB && gb < cbtot) {
+        float v[8];
+        unpack8<F16>(c[i], v);
+        if (rawp) *(pu32x4*)(rawp + (long)gb * oplane) = c[i];
+        if (L.norm_w) {
+          const f32x4 w0 = *(const f32x4*)(L.norm_w + gb * 8), w1 = *(const f32x4*)(L.norm_w + gb * 8 + 4);
+          const float wn[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = wn[j] * (v[j] * rstd);
+        }
+        if (L.mod == MOD_IMAGE) {
+          const float* scp = L.mod_scale + (long)img * L.mod_stride + gb * 8;
+          const float* shp = L.mod_shift + (long)img * L.mod_stride + gb * 8;
+          const f32x4 s0 = *(const f32x4*)scp, s1 = *(const f32x4*)(scp + 4), h0 = *(const f32x4*)shp, h1 = *(const f32x4*)(shp + 4);
+          const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+          const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * (1.0f + sc[j]) + sh[j];
+        } else if (L.mod == MOD_VOXEL) {
+          float sc[8], sh[8];
+          unpack8<F16>(msc[ii], sc);
+          unpack8<F16>(msh[ii], sh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * (1.0f + sc[j]) + sh[j];
+        }
+        if (L.act) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * __frcp_rn(1.0f + __expf(-v[j]));
+        }
+        *(pu32x4*)(outp + (long)gb * oplane) = pack8<F16>(v);
+      }
+    }
+  }
+  if (L.pad_blocks && (WS == 1 || wv == 0)) {
+    for (int pb = 0; pb < L.pad_blocks; ++pb) {
+      *(pu32x4*)(outp + (long)(cbtot + pb) * oplane) = pu32x4{0u, 0u, 0u, 0u};
+      if (rawp) *(pu32x4*)(rawp + (long)(cbtot + pb) * oplane) = pu32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
+// variant: 0 = automatic, 1 = prep_kernel (the generic form), 2 = prep_h16_kernel with one wave per 64 voxels, 3 = prep_h16_kernel
+// with the four waves of a workgroup splitting the channel blocks
+static int g_prep_variant = 0;
+void set_prep_variant(int v) { g_prep_variant = v; }
+
+template <bool F16>
+static bool launch_prep_h16(const PrepLaunch& L, hipStream_t s, int variant) {
+  PrepArgs pa; pa.L = L;
+  const long vox = (long)L.N * L.Z * L.S * L.S;
+  int cbtot = 0;
+  for (int k = 0; k < L.nsrc; ++k) cbtot += L.src[k].Cb;
+  // measured on the test_brn tile shapes (tools/bench_prep.py, profiles/r02_bench_prep.txt): the one-wave form wins for up to 12
+  // channel blocks on the fine levels, the split form everywhere else
+  bool one = cbtot <= 12 && vox / 256 >= 2048;
+  if (variant == 2) { if (cbtot > 32) return false; one = true; }
+  if (variant == 3) one = false;
+  if (one) {
+    const unsigned grid = (unsigned)((vox + 255) / 256);
+    if (cbtot <= 8) hipLaunchKernelGGL((prep_h16_kernel<1, 8, F16>), dim3(grid), dim3(256), 0, s, pa);
+    else if (cbtot <= 16) hipLaunchKernelGGL((prep_h16_kernel<1, 16, F16>), dim3(grid), dim3(256), 0, s, pa);
+    else hipLaunchKernelGGL((prep_h16_kernel<1, 32, F16>), dim3(grid), dim3(256), 0, s, pa);
+  } else {
+    if (cbtot > 160) return false;
+    const unsigned grid = (unsigned)((vox + 63) / 64);
+    if (cbtot <= 32) hipLaunchKernelGGL((prep_h16_kernel<4, 8, F16>), dim3(grid), dim3(256), 0, s, pa);
+    else if (cbtot <= 64) hipLaunchKernelGGL((prep_h16_kernel<4, 16, F16>), dim3(grid), dim3(256), 0, s, pa);
+    else hipLaunchKernelGGL((prep_h16_kernel<4, 40, F16>), dim3(grid), dim3(256), 0, s, pa);
+  }
+  return true;
+}
+
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s) {
+  static const int env_form = getenv("TM_PREP_FORM") ? atoi(getenv("TM_PREP_FORM")) : 0;       // A/B timing only
+  const int form = g_prep_variant ? g_prep_variant : env_form;
+  if (form != 1 && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample != RS_DOWN2 &&
+      (L.mod != MOD_VOXEL || L.mod_scale_h)) {
+    if (L.h_f16 ? launch_prep_h16<true>(L, s, form) : launch_prep_h16<false>(L, s, form)) return hipGetLastError();
+  }
+
   PrepArgs pa; pa.L = L;
   const long vox = (long)L.N * L.Z * L.S * L.S;
   const unsigned grid = (unsigned)((vox + 63) / 64);

@@ -1570,6 +1570,56 @@ extern "C" int tm_op_conv1_concat(const void* const* x_cb8, const int* cin, cons
   if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv1 concat execution: %s", hipGetErrorString(e2));
   return TM_OK;
 }
+extern "C" int tm_op_prep_h16(const void* const* src_h16, const int* src_c, const int* collage, int nsrc, int N, int Z, int S,
+                              int p1, int p2, int up2, const void* norm_w_dev, int c_real, int mod, const void* mod_scale,
+                              const void* mod_shift, long mod_stride, int per_image, int act, int dtype, int variant,
+                              void* out_h16, void* raw_h16, int iters, float* elapsed_ms, void* stream) {
+  if (!src_h16 || !src_c || !collage || !out_h16 || nsrc < 1 || nsrc > 3 || iters < 1) return fail(TM_ERR_ARG, "bad argument");
+  if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
+  if (mod != MOD_NONE && (!mod_scale || !mod_shift)) return fail(TM_ERR_ARG, "modulation tensors missing");
+  hipStream_t st = (hipStream_t)stream;
+  bool any_col = false;
+  for (int i = 0; i < nsrc; ++i) any_col = any_col || collage[i];
+  const int q = any_col ? (p1 - 1) * (p2 - 1) : 1;
+  if (any_col && (p1 < 2 || p2 < 2 || N % q)) return fail(TM_ERR_ARG, "collage needs N = b * (p1-1) * (p2-1)");
+  if (up2 && (any_col || (S & 1))) return fail(TM_ERR_ARG, "up2 takes plain sources and an even S");
+  const int Ss = up2 ? S / 2 : S;
+  PrepLaunch P;
+  P.nsrc = nsrc;
+  int cbtot = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    const int cb = (src_c[i] + 7) / 8;
+    P.src[i].p = (const float*)src_h16[i]; P.src[i].Cb = cb; P.src[i].collage = collage[i] ? 1 : 0;
+    P.src[i].nstride = (long)cb * Z * Ss * Ss * 8;
+    cbtot += cb;
+  }
+  const int cbe = (cbtot + 1) / 2 * 2;
+  P.src_h = 1; P.h_f16 = dtype == TM_DTYPE_F16;
+  P.resample = up2 ? RS_UP2 : RS_SAME; P.N = N; P.Z = Z; P.S = S; P.p1 = p1; P.p2 = p2;
+  P.norm_w = (const float*)norm_w_dev; P.inv_c = 1.0f / (float)c_real; P.act = act; P.per_image = per_image > 0 ? per_image : 1;
+  P.mod = mod; P.mod_stride = mod_stride;
+  if (mod == MOD_IMAGE) { P.mod_scale = (const float*)mod_scale; P.mod_shift = (const float*)mod_shift; }
+  if (mod == MOD_VOXEL) { P.mod_scale_h = (const uint16_t*)mod_scale; P.mod_shift_h = (const uint16_t*)mod_shift; }
+  P.out_h = (uint16_t*)out_h16; P.out_h_nstride = (long)cbe * Z * S * S * 8; P.pad_blocks = cbe - cbtot;
+  if (raw_h16) { P.raw_h = (uint16_t*)raw_h16; P.raw_h_nstride = P.out_h_nstride; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (elapsed_ms) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
+  set_prep_variant(variant);
+  hipError_t e = launch_prep(P, st);                                   // warm-up / the result
+  if (elapsed_ms && e == hipSuccess) e = hipEventRecord(e0, st);
+  for (int i = 1; i < iters && e == hipSuccess; ++i) e = launch_prep(P, st);
+  if (elapsed_ms && e == hipSuccess) e = hipEventRecord(e1, st);
+  set_prep_variant(0);
+  hipError_t e2 = hipStreamSynchronize(st);
+  if (elapsed_ms) {
+    if (e == hipSuccess && e2 == hipSuccess && iters > 1) { (void)hipEventElapsedTime(elapsed_ms, e0, e1); *elapsed_ms /= (float)(iters - 1); }
+    else *elapsed_ms = 0.f;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "prep launch: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "prep execution: %s", hipGetErrorString(e2));
+  return TM_OK;
+}
 extern "C" int tm_op_window_attn(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_dev,
                                  const void* kw_dev, void* out, int N, int C, int Z, int S, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -204,6 +204,95 @@ def test_conv1_concat_collage_input_exact_integers(b, p1, p2, cins, flags, Cout,
     assert torch.equal(got.cpu(), ref), util.report("conv1 concat " + dtype, got, ref)
 
 
+# (b, p1, p2, cins, collage flags, S, up2, mod, with norm)
+PREP_CASES = [
+    (2, 3, 3, (64, 32), (0, 0), 16, False, 0, True),            # encoder block input: cat(h, rna)
+    (1, 2, 4, (128, 64, 32), (1, 1, 1), 8, False, 0, True),     # decoder block input, every source re-tiled
+    (2, 3, 2, (40, 24, 229), (0, 1, 1), 8, False, 0, True),     # odd block counts, 3 pad channels inside the concat
+    (5, 2, 2, (64,), (0,), 16, True, 0, True),                  # up block: nearest x2 of a single source
+    (3, 2, 2, (256,), (0,), 8, False, 1, True),                 # out_layers of a Cout > 128 block: per-image scale / shift
+    (2, 2, 2, (128,), (0,), 16, False, 2, True),                # AttnBlock modulate: per-voxel scale / shift, no SiLU
+    (2, 2, 3, (229,), (1,), 8, False, 0, False),                # SiLU(cond) of the collage decoder: no norm
+    (1, 2, 2, (512, 512, 229), (0, 1, 1), 8, False, 0, True)]   # 157 channel blocks (the widest concat of the model)
+
+
+@pytest.mark.parametrize("b,p1,p2,cins,flags,S,up2,mod,norm", PREP_CASES)
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_prep_h16_forms_vs_torch(b, p1, p2, cins, flags, S, up2, mod, norm, variant, dtype):
+    """cat + to_collage / Upsample + LlamaRMSNorm + modulate + SiLU on the 16-bit stream (model/unet_ours.py:325-341,384,418,
+    model/MBAblocks.py:21-43,254-261,356-367,484-489,608-614): every kernel form against fp32 torch on the same 16-bit
+    inputs, to one 16-bit ulp (the forms differ in the order of the sum of squares and use the hardware exp / rcp)."""
+    from oracle import teramind_cpu as tc
+    if variant == 2 and sum((c + 7) // 8 for c in cins) > 32:
+        pytest.skip("one-wave form holds at most 32 channel blocks")
+    td = util.H16[dtype][1]
+    g = torch.Generator().manual_seed(5)
+    Ne, Nd = b * p1 * p2, b * (p1 - 1) * (p2 - 1)
+    any_col = any(flags)
+    N = Nd if any_col else Ne
+    Ss = S // 2 if up2 else S
+    xs, parts = [], []
+    for c, f in zip(cins, flags):
+        x = (torch.randn((Ne if f else N, c, 2, Ss, Ss), generator=g) * 1.5).to(td).float()
+        xs.append(x)
+        y = tc.collage(x, b, p1, p2) if f else x
+        if up2:
+            y = y.repeat_interleave(2, 3).repeat_interleave(2, 4)
+        parts.append(y)
+    xcat = torch.cat(parts, 1)
+    Ct = xcat.shape[1]
+    ws = [torch.randn((c,), generator=g) * 0.3 + 1.0 for c in cins] if norm else None
+    ref = xcat
+    if norm:
+        ref = torch.cat(ws) [None, :, None, None, None] * (xcat * torch.rsqrt(xcat.pow(2).mean(1, keepdim=True) + 1e-6))
+    per_image = N // b
+    scale = shift = None
+    if mod == 1:
+        scale, shift = torch.randn((b, Ct), generator=g) * 0.5, torch.randn((b, Ct), generator=g) * 0.5
+        ix = torch.arange(N) // per_image
+        ref = ref * (1 + scale[ix][:, :, None, None, None]) + shift[ix][:, :, None, None, None]
+    elif mod == 2:
+        scale = (torch.randn(xcat.shape, generator=g) * 0.5).to(td).float()
+        shift = (torch.randn(xcat.shape, generator=g) * 0.5).to(td).float()
+        ref = ref * (1 + scale) + shift
+    act = mod != 2
+    if act:
+        ref = F.silu(ref)
+    got, raw, _ = util.prep_h16([x.to(DEV) for x in xs], cins, flags, b, p1, p2, S, up2=up2, norm_w=ws, mod=mod, scale=scale,
+                                shift=shift, per_image=per_image, act=act, dtype=dtype, variant=variant, want_raw=True)
+    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    o = 0
+    for i, c in enumerate(cins):
+        r = ref[:, o:o + c]
+        err = (got[i].cpu() - r).abs()
+        assert bool((err <= ulp * r.abs() + 1e-6).all()), util.report(f"prep {dtype} v{variant} src{i}", got[i], r)
+        assert torch.equal(raw[i].cpu(), xcat[:, o:o + c]), "raw copy must be the gathered input, bit for bit"
+        o += c
+
+
+@pytest.mark.parametrize("cins,flags,mod", [((64, 32), (0, 0), 0), ((128, 64, 32), (1, 1, 1), 0), ((128,), (0,), 2), ((229,), (0,), 0)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_prep_h16_forms_bit_identical(cins, flags, mod, dtype):
+    """The launcher picks the one-wave or the split form of prep_h16_kernel by the size of the call; both add the sum of
+    squares in the same order, so the choice never changes a bit (a patch inside a tile-sized batch == the patch alone)."""
+    td = util.H16[dtype][1]
+    g = torch.Generator().manual_seed(9)
+    b, p1, p2, S = 2, 3, 3, 16
+    any_col = any(flags)
+    Ne, N = b * p1 * p2, (b * (p1 - 1) * (p2 - 1) if any_col else b * p1 * p2)
+    xs = [(torch.randn((Ne if f else N, c, 2, S, S), generator=g) * 2).to(td).float().to(DEV) for c, f in zip(cins, flags)]
+    ws = [torch.randn((c,), generator=g) * 0.3 + 1.0 for c in cins]
+    scale = shift = None
+    if mod == 2:
+        scale = (torch.randn((N, sum(cins), 2, S, S), generator=g) * 0.5).to(td).float()
+        shift = (torch.randn((N, sum(cins), 2, S, S), generator=g) * 0.5).to(td).float()
+    outs = [util.prep_h16(xs, cins, flags, b, p1, p2, S, norm_w=ws, mod=mod, scale=scale, shift=shift, per_image=N // b,
+                          act=mod != 2, dtype=dtype, variant=v)[0] for v in (2, 3)]
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
 def test_conv27_bf16_random_vs_bf16_rounded_reference():
     g = torch.Generator().manual_seed(17)
     N, Cin, Cout, S = 2, 741, 512, 8

@@ -158,3 +158,55 @@ def write_gene_dir(gdir, rows, cols, total_slc=50, nnz=20000, seed=0):
             v = (r * 256, r * 256 + 256, c * 256, c * 256 + 256, r * 256 - half, r * 256 + 256 + half, c * 256 - half, c * 256 + 256 + half)
             data, crd, shape = synthetic_gene_coo(r, c, total_slc, nnz, seed)
             formats.write_gene_npz(os.path.join(gdir, "_".join(map(str, v)) + ".npz"), data, crd, shape)
+
+
+def prep_h16(xs, cins, flags, b, p1, p2, S, up2=False, norm_w=None, mod=0, scale=None, shift=None, per_image=1, act=True,
+             dtype="bf16", variant=0, want_raw=False, iters=1):
+    """The 16-bit block-input pass (tm_op_prep_h16).  xs: NCDHW fp32 sources (cuda), handed over as 16-bit CB8 tensors;
+    norm_w: list of per-source fp32 weight vectors (or None); mod 1: scale / shift [images][C] fp32, mod 2: NCDHW tensors of
+    the output geometry (handed over 16-bit).  Returns (list of per-source fp32 NCDHW slices of the output, the same for the
+    raw copy or None, mean ms per launch)."""
+    dev = xs[0].device
+    td = H16[dtype][1]
+    any_col = any(flags)
+    N = b * (p1 - 1) * (p2 - 1) if any_col else xs[0].shape[0]
+    Z = xs[0].shape[2]
+    xc = [to_cb8_h16(x, dtype) for x in xs]
+    cbs = [(c + 7) // 8 for c in cins]
+    cbtot = sum(cbs)
+    cbe = (cbtot + 1) // 2 * 2
+    nw = None
+    if norm_w is not None:
+        nw = torch.zeros(cbtot * 8, dtype=torch.float32, device=dev)
+        o = 0
+        for w, c, cb in zip(norm_w, cins, cbs):
+            nw[o:o + c] = w.to(dev)
+            o += cb * 8
+    sc = sh = None
+    stride = 0
+    if mod == 1:
+        sc, sh = scale.contiguous().float().to(dev), shift.contiguous().float().to(dev)
+        stride = sc.shape[1]
+    elif mod == 2:
+        sc, sh = to_cb8_h16(scale.to(dev), dtype), to_cb8_h16(shift.to(dev), dtype)
+        stride = sc[0].numel()
+    out = torch.full((N, cbe, Z, S, S, 8), 7.0, dtype=td, device=dev)
+    raw = torch.full((N, cbe, Z, S, S, 8), 7.0, dtype=td, device=dev) if want_raw else None
+    ptrs = (C.c_void_p * len(xc))(*[t.data_ptr() for t in xc])
+    cin = (C.c_int * len(xc))(*cins)
+    col = (C.c_int * len(xc))(*[int(f) for f in flags])
+    ms = C.c_float(0.0)
+    _lib.check(_lib.lib().tm_op_prep_h16(ptrs, cin, col, len(xc), N, Z, S, p1, p2, int(up2), _lib.ptr(nw), sum(cins), mod,
+                                         _lib.ptr(sc), _lib.ptr(sh), stride, per_image, int(act), H16[dtype][0], variant,
+                                         _lib.ptr(out), _lib.ptr(raw), iters, C.byref(ms), _lib.current_stream_ptr()),
+               "tm_op_prep_h16")
+
+    def split(t):
+        res, o = [], 0
+        for c, cb in zip(cins, cbs):
+            res.append(from_cb8(t[:, o:o + cb].float().contiguous(), c))
+            o += cb
+        pad = t[:, cbtot:]
+        assert not pad.numel() or float(pad.float().abs().max()) == 0.0, "pad blocks must be zero"
+        return res
+    return split(out), (split(raw) if want_raw else None), ms.value
