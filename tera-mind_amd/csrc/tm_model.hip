@@ -95,6 +95,8 @@ struct tm_model {
   const float *emb_w = nullptr, *emb_b = nullptr;
   GeneW gene;
   ConvW downz, pyr[3];
+  ConvW pyr16[3];                                    // 16-bit modes: the pyramid convs as 27-tap 16-bit convs (centre z slice)
+  const uint16_t* pyrh[3] = {nullptr, nullptr, nullptr};
   DirectW stem, head, downz_d;       // downz_d: direct-conv form of down_z when the MFMA form does not apply
   bool downz_mfma = true;            // kz == 3 on a 4 x 4 (checkpoint config) or 8 x 8 gene grid
   bool gene_mfma = true;             // D == 64, G <= 232, no gene index table: fused MFMA gene-attention kernel
@@ -390,14 +392,23 @@ static void pack_conv(tm_model* m, Packer& pk, std::vector<Fix>& fx, ConvW& cw, 
 // 3x3x3 conv for the bf16 path: bf16 packed weights (tm_conv_bf16.hip layout) + the fp32 bias
 static void pack_conv_h(tm_model* m, Packer& pk, std::vector<Fix>& fx, std::vector<FixH>& fxh, ConvW& cw,
                         const uint16_t** wslot, const std::string& wkey, const std::string& bkey, int Cout,
-                        const std::vector<int>& seg) {
-  int cbi = 0;
-  for (int c : seg) cbi += (c + 7) / 8;
+                        const std::vector<int>& seg, bool inplane = false) {
+  int cbi = 0, cin = 0;
+  for (int c : seg) { cbi += (c + 7) / 8; cin += c; }
+  // inplane: a Conv3d(k = (1,3,3), pad (0,1,1)) run by the 3x3x3 kernel -- its 9 taps sit in the centre z slice, the z - 1
+  // and z + 1 slices are zero
+  std::vector<float> w27;
+  if (inplane) {
+    const std::vector<float>& w9 = P(m, wkey);
+    w27.assign((size_t)Cout * cin * 27, 0.f);
+    for (size_t i = 0; i < (size_t)Cout * cin; ++i)
+      for (int t = 0; t < 9; ++t) w27[i * 27 + 9 + t] = w9[i * 9 + t];
+  }
   cw.Cout = Cout; cw.Cbi = cbi; cw.taps = 27; cw.ntile = (Cout + 63) / 64; cw.w = nullptr;
   const size_t elems = conv_bf16_pack_elems(Cout, cbi);
   size_t off = pk.reserve((elems + 1) / 2);
-  (m->cfg.dtype == TM_DTYPE_F16 ? conv_f16_pack_host : conv_bf16_pack_host)(P(m, wkey).data(), Cout, seg.data(), (int)seg.size(),
-                                                                            (uint16_t*)(pk.buf.data() + off));
+  (m->cfg.dtype == TM_DTYPE_F16 ? conv_f16_pack_host : conv_bf16_pack_host)(inplane ? w27.data() : P(m, wkey).data(), Cout, seg.data(),
+                                                                            (int)seg.size(), (uint16_t*)(pk.buf.data() + off));
   fxh.push_back({wslot, off});
   size_t boff = pk.reserve((size_t)cw.ntile * 64);
   const std::vector<float>& b = P(m, bkey);
@@ -527,9 +538,13 @@ extern "C" int tm_model_finalize(tm_model* m) {
     }
   }
   if (!c.vis_only) {
-    for (int rid = 1; rid < 4; ++rid)
+    for (int rid = 1; rid < 4 && !is_h16(c.dtype); ++rid)
       pack_conv(m, pk, fx, m->pyr[rid - 1], "rna_blocks." + std::to_string(rid) + ".1.weight",
                 "rna_blocks." + std::to_string(rid) + ".1.bias", m->rw[rid], {m->rw[rid - 1]}, 9);
+    if (is_h16(c.dtype))
+      for (int rid = 1; rid < 4; ++rid)
+        pack_conv_h(m, pk, fx, fxh, m->pyr16[rid - 1], &m->pyrh[rid - 1], "rna_blocks." + std::to_string(rid) + ".1.weight",
+                    "rna_blocks." + std::to_string(rid) + ".1.bias", m->rw[rid], {m->rw[rid - 1]}, true);
     pack_direct(m, pk, fx, m->stem, "input_blocks.0.0", c.net_ch, c.n_stain, 1, 3, 3);
     pack_direct(m, pk, fx, m->head, "out.2", c.n_stain, c.net_ch, 1, 3, 3);
     pack_raw(pk, fx, &m->out_norm, P(m, "out.0.weight"));
@@ -752,7 +767,8 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
 
 // y: geometry of the output; y16: `y.p` is a 16-bit stream tensor (written as such); res16: 16-bit stream residual
 static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res16, int cin_real,
-                       const TVH* fuse_a2 = nullptr, const ResW* rw = nullptr, int per_image = 1, bool y16 = false) {
+                       const TVH* fuse_a2 = nullptr, const ResW* rw = nullptr, int per_image = 1, bool y16 = false,
+                       bool count = true) {
   if (cx.dry) return;
   ConvLaunchH L;
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y;
@@ -764,7 +780,7 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
     L.fuse_norm = 1; L.a2 = *fuse_a2; L.norm_w = rw->n2; L.per_image = per_image;
     L.mod_scale = cx.ss + rw->emb_off; L.mod_shift = cx.ss + rw->emb_off + rw->cout; L.mod_stride = m->emb_tot;
   }
-  const bool prof = m->prof_on;
+  const bool prof = m->prof_on && count;    // count = false: not a ResBlock 3x3x3 conv (the in-plane pyramid convs: 9 real taps)
   if (prof) {
     if (m->prof_used == m->prof_ev.size()) {
       hipEvent_t a, b;
@@ -1075,14 +1091,76 @@ static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
                                         c.rna_slc, gws, cx.s));
     cx.top = mark;                                               // scratch only (the stream orders its reuse)
   }
-  // fp32 levels: the outputs themselves in fp32 mode, scratch in the 16-bit modes (the RNA path stays fp32: 0.2 % of the FLOPs)
-  TV rl[4], rs[3];
-  S = m->gn * 2;
-  for (int i = 0; i < 4; ++i) { rl[i] = h16 ? cx.tensor(Ne, m->rw[i], Z, S) : R.rl[i]; S *= 2; }
-  S = m->gn * 2;
-  for (int i = 0; i < 3; ++i) { rs[i] = h16 ? cx.tensor(Ne, m->rw[i], Z, S) : R.rs[i]; S *= 2; }
   const bool was_dry = cx.dry;
   cx.dry = !run;
+  if (h16) {
+    // 16-bit modes: gene attention and down_z stay fp32 (they read the fp32 gene counts; < 0.3 % of the FLOPs), level 0
+    // enters the 16-bit stream behind down_z, and the three SiLU -> Conv3d(1,3,3) -> Upsample stages
+    // (model/unet_ours.py:290-295) run as 16-bit convs like every other conv under the reference's autocast: the in-plane
+    // conv is the 3x3x3 kernel on weights whose z - 1 / z + 1 slices are zero, its output leaves at the conv's resolution
+    // and ONE pass of the block-input kernel writes both the x2 level (raw copy) and SiLU of it (the next conv's input).
+    const int h_f16 = c.dtype == TM_DTYPE_F16;
+    int S0 = m->gn * 2;
+    TV rl0 = cx.tensor(Ne, m->rw[0], Z, S0);
+    if (m->downz_mfma) run_conv(cx, tok, m->downz, rl0, nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
+    else {
+      const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl0);
+      if (run) cx.check(hipMemsetAsync(rl0.p, 0, (size_t)Ne * rl0.nstride * sizeof(float), cx.s));     // pad channels
+      run_direct(cx, m->downz_d, tok.p, ax, rl0.p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+    }
+    const int cbe0 = (rl0.Cb + 1) / 2 * 2;
+    TVH act = cx.tensor_h(Ne, cbe0, Z, S0);                        // SiLU(level) = the conv input (even block count)
+    if (run) {
+      PrepLaunch P;                                                // fp32 level 0 -> the 16-bit stream tensor
+      P.nsrc = 1;
+      P.src[0].p = rl0.p; P.src[0].nstride = rl0.nstride; P.src[0].Cb = rl0.Cb;
+      P.N = Ne; P.Z = Z; P.S = S0; P.h_f16 = h_f16;
+      P.out_h = (uint16_t*)R.rl[0].p; P.out_h_nstride = R.rl[0].nstride;
+      cx.check(launch_prep(P, cx.s));
+      PrepLaunch Q;                                                // SiLU of it, pair-padded
+      Q.nsrc = 1; Q.src_h = 1; Q.h_f16 = h_f16;
+      Q.src[0].p = R.rl[0].p; Q.src[0].nstride = R.rl[0].nstride; Q.src[0].Cb = R.rl[0].Cb;
+      Q.N = Ne; Q.Z = Z; Q.S = S0; Q.act = 1;
+      Q.out_h = act.p; Q.out_h_nstride = act.nstride; Q.pad_blocks = act.Cb - R.rl[0].Cb;
+      cx.check(launch_prep(Q, cx.s));
+    }
+    int S = S0;
+    for (int i = 1; i < 4; ++i) {
+      TV y = cx.tensor_s(Ne, m->rw[i], Z, S);                      // conv output at the conv's resolution (16-bit)
+      run_conv_h(cx, act, m->pyrh[i - 1], m->pyr16[i - 1], y, nullptr, m->rw[i - 1], nullptr, nullptr, 1, true, false);
+      S *= 2;
+      TVH nxt;
+      if (i < 3) nxt = cx.tensor_h(Ne, (R.rl[i].Cb + 1) / 2 * 2, Z, S);
+      if (run) {
+        PrepLaunch U;                                              // Upsample: level i (raw) and SiLU(level i)
+        U.nsrc = 1; U.src_h = 1; U.h_f16 = h_f16; U.resample = RS_UP2;
+        U.src[0].p = y.p; U.src[0].nstride = y.nstride; U.src[0].Cb = y.Cb;
+        U.N = Ne; U.Z = Z; U.S = S;
+        if (i < 3 && nxt.Cb == R.rl[i].Cb) {
+          U.act = 1; U.out_h = nxt.p; U.out_h_nstride = nxt.nstride;
+          U.raw_h = (uint16_t*)R.rl[i].p; U.raw_h_nstride = R.rl[i].nstride;
+          cx.check(launch_prep(U, cx.s));
+        } else {
+          U.out_h = (uint16_t*)R.rl[i].p; U.out_h_nstride = R.rl[i].nstride;
+          cx.check(launch_prep(U, cx.s));
+          if (i < 3) {                                             // odd block count: the pair-padded SiLU copy on its own
+            PrepLaunch Q;
+            Q.nsrc = 1; Q.src_h = 1; Q.h_f16 = h_f16;
+            Q.src[0].p = R.rl[i].p; Q.src[0].nstride = R.rl[i].nstride; Q.src[0].Cb = R.rl[i].Cb;
+            Q.N = Ne; Q.Z = Z; Q.S = S; Q.act = 1;
+            Q.out_h = nxt.p; Q.out_h_nstride = nxt.nstride; Q.pad_blocks = nxt.Cb - R.rl[i].Cb;
+            cx.check(launch_prep(Q, cx.s));
+          }
+        }
+      }
+      act = nxt;
+    }
+    cx.dry = was_dry;
+    cx.top = rna_mark;
+    return;
+  }
+  TV* rl = R.rl;
+  TV* rs = R.rs;
   if (m->downz_mfma) run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
   else {
     // generic (kz, gn): direct conv straight from / to the CB8 tensors, nearest x2 fused into the store
@@ -1100,16 +1178,6 @@ static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
       cx.check(launch_prep(P, cx.s));
     }
     run_conv(cx, rs[i - 1], m->pyr[i - 1], rl[i], nullptr, nullptr, EPI_UP2, 0, ZM_INPLANE);   // SiLU -> conv -> Upsample
-  }
-  if (h16 && run) {                                               // the four levels enter the 16-bit activation stream here
-    for (int i = 0; i < 4; ++i) {
-      PrepLaunch P;
-      P.nsrc = 1;
-      P.src[0].p = rl[i].p; P.src[0].nstride = rl[i].nstride; P.src[0].Cb = rl[i].Cb;
-      P.N = Ne; P.Z = Z; P.S = rl[i].H; P.h_f16 = c.dtype == TM_DTYPE_F16;
-      P.out_h = (uint16_t*)R.rl[i].p; P.out_h_nstride = R.rl[i].nstride;
-      cx.check(launch_prep(P, cx.s));
-    }
   }
   cx.dry = was_dry;
   cx.top = rna_mark;                                              // tok / fp32 scratch are dead (the stream orders reuse)
