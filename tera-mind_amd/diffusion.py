@@ -245,6 +245,30 @@ class SpacedDiffusionBeatGans:
 # ------------------------------------------------------------------------------------------
 # thin wrappers of the C-ABI kernels
 # ------------------------------------------------------------------------------------------
+def gen_sample(model, sampler: "SpacedDiffusionBeatGans", pnm_w: int, pnm_h: int, x_start: torch.Tensor, r_start, patch_size: int,
+               sample_size: int, *, x_T: Optional[torch.Tensor] = None, start: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The sampling half of `LitModel.gen_sample` (experiment.py:293-330; the picture grid / TensorBoard part behind it is
+    not part of the path): the patch-shaped noise tensor that fixes the batch (`sample_size * pnm_w * pnm_h` patches ->
+    `bat` images), the first `bat` images' entries of the COO gene triple `(dat, crd, ssz)` (:311-318), the patch-corner
+    grid `pos` (:303-308, unused by the `ours` model) and ONE `sampler.sample` call in mode A (:325-330).
+    `x_T` replaces the reference's `torch.randn` patch tensor (only its batch and patch size matter to the sampler);
+    `start` pins the initial state the sampler would draw itself (base.py:566)."""
+    dev = model.device if hasattr(model, "device") else next(model.parameters()).device
+    if x_T is None:
+        x_T = torch.randn(sample_size * pnm_w * pnm_h, x_start.shape[1], patch_size, patch_size, device=dev)
+    bat = len(x_T) // pnm_w // pnm_h
+    xs = x_start[:bat]
+    gx = torch.linspace(0, pnm_w, pnm_w + 1, device=dev)
+    gy = torch.linspace(0, pnm_h, pnm_h + 1, device=dev)
+    xx, yy = torch.meshgrid(gx, gy, indexing="ij")
+    pos = torch.stack([xx, yy], dim=-1).flatten(0, 1).repeat(xs.shape[0], 1)
+    dat, crd, ssz = r_start
+    crd = crd.long()
+    keep = crd[0] < bat
+    rs = (dat[keep], crd[:, keep], torch.Size([bat, ssz[1], ssz[2], ssz[3]]))
+    return sampler.sample(model=model, shape=xs.shape, noise=x_T.detach(), r_start=rs, patch_size=patch_size, pos=pos, x_T=start)
+
+
 def pad_patchify(img: torch.Tensor, ps: int, pad_value: float = 0.0) -> torch.Tensor:
     """F.pad(img, ps/2) + 'b c (p1 h) (p2 w) -> (b p1 p2) c h w' (base.py:606-607)."""
     img = img.float().contiguous()

@@ -88,6 +88,21 @@ def test_sample_accepts_sparse_coo_rna_like_gen_sample():
     assert torch.equal(a, b)
 
 
+def test_gen_sample_shim_crops_the_coo_batch():
+    """LitModel.gen_sample (experiment.py:293-330): the noise tensor's patch count fixes the batch, the COO triple is cut to
+    those images, one mode-A sample() call.  Two images' genes handed over, one image sampled == sample() on image 0."""
+    from teramind_amd.diffusion import gen_sample
+    rna_p = synth.gene_counts("traj/rna", (8, 4, 4, 2000), 0)                    # 2 images x (2 x 2) padded patches
+    grid = rna_p.reshape(2, 2, 2, 4, 4, 2000).permute(0, 1, 3, 2, 4, 5).reshape(2, 8, 8, 2000)
+    smp = SpacedDiffusionBeatGans(3, "ddim")
+    xT = synth.normal("coo/xT", (1, 4, 64, 64), 0)
+    x_start = torch.zeros(2, 4, 64, 64)
+    a = gen_sample(model(), smp, 1, 1, x_start, synth.dense_to_coo(grid), 64, sample_size=1, start=xT)
+    b = smp.sample(model=model(), shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), patch_size=64, x_T=xT,
+                   r_start=rna_p[:4].to(DEV))
+    assert a.shape == (1, 4, 64, 64) and torch.equal(a, b)
+
+
 def test_attention_maps_vs_reference():
     gold = np.load(os.path.join(G, "attn_maps.npz"))
     cfg = PathConfig()
