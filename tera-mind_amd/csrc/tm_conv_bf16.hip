@@ -188,7 +188,10 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
         ok[mt] = cob < a.Cob && ooff[mt] >= 0;
         pl[mt] = ok[mt] ? (long)cob * a.y_plane + ooff[mt] : 0;
         if (a.res_h) rb[mt] = *(const h16x8*)(a.res_h + (ok[mt] ? (long)on[mt] * a.res_h_nstride : 0) + pl[mt]);
-        if (GATE && a.gate_h) gb[mt] = *(const h16x8*)(a.gate_h + (ok[mt] ? (long)on[mt] * a.gate_h_nstride : 0) + pl[mt]);
+        if (GATE && a.gate_h) {
+          const long gpl = !a.gate_ls ? pl[mt] : (ok[mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.gate_ls) : 0);
+          gb[mt] = *(const h16x8*)(a.gate_h + (ok[mt] ? (long)on[mt] * a.gate_h_nstride : 0) + gpl);
+        }
       }
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
       if (cob < a.Cob) { b0 = *(const f32x4*)(a.bias + (long)cob * 8); b1 = *(const f32x4*)(a.bias + (long)cob * 8 + 4); }
@@ -762,7 +765,7 @@ struct WAGeo {
   static constexpr int CH = 64;                     // channels per V stage
   static constexpr int P_BYTES = 128 * PP;          // [128 queries of the workgroup][T keys]
   static constexpr int VT_BYTES = WPW * CH * PP;    // one stage, all windows of the workgroup
-  static constexpr int MISC_FLOATS = 128 /*tokoff*/ + 128 /*rq*/ + 128 /*rk*/ + 512 /*w2*/;
+  static constexpr int MISC_FLOATS = 128 /*tokoff*/ + 128 /*tokoff of k / v*/ + 128 /*rq*/ + 128 /*rk*/ + 512 /*w2*/;
   static constexpr int LDS_BYTES = P_BYTES + 2 * VT_BYTES + MISC_FLOATS * 4;
 };
 
@@ -772,6 +775,7 @@ struct WinArgsH {
   uint16_t* o; long o_ns;
   int C, S;
   long plane;                                       // elements per channel block
+  int kv_half;                                      // k / v live at half the in-plane resolution (token (z, y, x) reads (z, y >> 1, x >> 1))
 };
 
 template <int T>
@@ -782,7 +786,8 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   unsigned char* Pl = smem;                                   // [128][PP]
   unsigned char* Vt = Pl + G::P_BYTES;                        // 2 x [WPW][CH][PP]
   int* tokoff = (int*)(Vt + 2 * G::VT_BYTES);                 // [128]: window-major, token-minor
-  float* rq = (float*)(tokoff + 128);
+  int* tokoff_kv = tokoff + 128;                              // the same tokens in the k / v tensors (half resolution or equal)
+  float* rq = (float*)(tokoff_kv + 128);
   float* rk = rq + 128;
   float* w2 = rk + 128;                                       // [C] q_norm.w * k_norm.w
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -790,6 +795,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   constexpr int NWG = 4 / G::WPW;                            // workgroups per patch (each covers WPW windows = 128 tokens)
   const int n = blockIdx.x / NWG;
   const int S = a.S, hs = S / 2, C = a.C, npair = C / 16;
+  const long kv_plane = a.kv_half ? a.plane >> 2 : a.plane;
   if (tid < 128) {
     const int win = (blockIdx.x % NWG) * G::WPW + tid / T;
     const int t = tid % T;
@@ -797,7 +803,9 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
     const int z = t / (hs * hs);
     const int r = t - z * hs * hs;
     const int yl = r / hs, xl = r - yl * hs;
-    tokoff[tid] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+    const int yy = wy * hs + yl, xx = wx * hs + xl;
+    tokoff[tid] = ((z * S + yy) * S + xx) * 8;
+    tokoff_kv[tid] = a.kv_half ? ((z * hs + (yy >> 1)) * hs + (xx >> 1)) * 8 : ((z * S + yy) * S + xx) * 8;
   }
   for (int c = tid; c < C; c += 256) w2[c] = a.qw[c] * a.kw[c];
   __syncthreads();
@@ -807,10 +815,11 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   {  // RMSNorm statistics of the 128 query and 128 key tokens (fp32 sums over the bf16 values)
     const bool isq = tid < 128;
     const int t = tid & 127;
-    const h16_t* p = (isq ? qb : kb) + tokoff[t];
+    const h16_t* p = isq ? qb + tokoff[t] : kb + tokoff_kv[t];
+    const long pp = isq ? a.plane : kv_plane;
     float ss = 0.f;
     for (int cb = 0; cb < C / 8; ++cb) {
-      const bf16x8 v8 = *(const bf16x8*)(p + (long)cb * a.plane);
+      const bf16x8 v8 = *(const bf16x8*)(p + (long)cb * pp);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float f = (float)v8[j]; ss += f * f; }
     }
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   const h16_t* qp = qb + tokoff[qtok] + (long)h * a.plane;
   const h16_t* kp[G::NW];
 #pragma unroll
-  for (int ct = 0; ct < G::NW; ++ct) kp[ct] = kb + tokoff[wbase + ct * 32 + i32] + (long)h * a.plane;
+  for (int ct = 0; ct < G::NW; ++ct) kp[ct] = kb + tokoff_kv[wbase + ct * 32 + i32] + (long)h * kv_plane;
   bf16x8 qn = *(const bf16x8*)qp, kn[G::NW];
 #pragma unroll
   for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)kp[ct];
@@ -845,10 +854,10 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
 #pragma unroll
     for (int ct = 0; ct < G::NW; ++ct) kf[ct] = kn[ct];
     if (kp2 + 1 < npair) {
-      const long po = (long)(kp2 + 1) * 2 * a.plane;
+      const long po = (long)(kp2 + 1) * 2 * a.plane, pk = (long)(kp2 + 1) * 2 * kv_plane;
       qn = *(const bf16x8*)(qp + po);
 #pragma unroll
-      for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)(kp[ct] + po);
+      for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)(kp[ct] + pk);
     }
 #pragma unroll
     for (int ct = 0; ct < G::NW; ++ct) acc[ct] = TM_MFMA16(kf[ct], qf, acc[ct]);
@@ -888,12 +897,12 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   // V staging: 512 items per stage = 64 token pairs x 8 channel blocks; thread owns items tid and tid + 256
   const int gp = tid & 63;                                    // token pair (workgroup numbering 2gp, 2gp+1)
   const int swin = (2 * gp) / T, st = (2 * gp) % T;
-  const h16_t* vs0 = vb + tokoff[2 * gp];
-  const h16_t* vs1 = vb + tokoff[2 * gp + 1];
+  const h16_t* vs0 = vb + tokoff_kv[2 * gp];
+  const h16_t* vs1 = vb + tokoff_kv[2 * gp + 1];
   const int scb = tid >> 6;                                   // channel blocks scb and scb + 4 of the stage
   bf16x8 vr[4];
   auto vload = [&](int c0) {
-    const long o0 = (long)(c0 / 8 + scb) * a.plane, o1 = o0 + 4 * a.plane;
+    const long o0 = (long)(c0 / 8 + scb) * kv_plane, o1 = o0 + 4 * kv_plane;
     vr[0] = *(const bf16x8*)(vs0 + o0); vr[1] = *(const bf16x8*)(vs1 + o0);
     vr[2] = *(const bf16x8*)(vs0 + o1); vr[3] = *(const bf16x8*)(vs1 + o1);
   };
@@ -1148,6 +1157,10 @@ hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, con
   a.C = q.Cb * 8; a.S = q.H; a.plane = (long)q.Z * q.H * q.W * 8;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
   if (a.C % 64 || a.C > 512 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
+  // k / v at half the in-plane resolution of q (the conditioning side of an AttnBlock is constant over 2 x 2 voxel blocks)
+  a.kv_half = (k.H * 2 == q.H) ? 1 : 0;
+  if ((!a.kv_half && k.H != q.H) || k.H != v.H || k.W != k.H || v.W != v.H) return hipErrorInvalidValue;
+  if (a.kv_half && ((q.H & 3) || (T != 128 && T != 64 && T != 32))) return hipErrorInvalidValue;
   if (T == 256 || T == 512) {
     if (a.C > 256) return hipErrorInvalidValue;
 #define TM_LAUNCHWL(T_)                                                                                     \
@@ -1307,6 +1320,12 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
   a.gate = L.gate ? L.gate->p : nullptr; a.gate_nstride = L.gate ? L.gate->nstride : 0;
   a.gate_h = L.gate_h ? L.gate_h->p : nullptr; a.gate_h_nstride = L.gate_h ? L.gate_h->nstride : 0;
+  if (L.gate_half) {
+    int ls = 0;
+    while ((1 << ls) < L.y.H) ++ls;
+    if (!L.gate_h || (1 << ls) != L.y.H || L.y.H != L.y.W || ls < 1) return hipErrorInvalidValue;
+    a.gate_ls = ls;
+  }
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = L.flags;
   a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
   a.res_h = L.res_h ? L.res_h->p : nullptr; a.res_h_nstride = L.res_h ? L.res_h->nstride : 0;

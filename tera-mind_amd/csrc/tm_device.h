@@ -69,7 +69,17 @@ struct ConvArgs {
   int Zin = 0, zoff = 0;            // conv3d NZI = 3: source plane = zo + zi + zoff, zero outside [0, Zin)
   const uint16_t* res_h = nullptr;  // 16-bit kernels only: 16-bit CB8 residual instead of `res` (the 16-bit activation stream)
   long res_h_nstride = 0;
+  // gate tensor at HALF the in-plane resolution ([N][Cob][Z][S/2][S/2][8], read at (z, y >> 1, x >> 1)): the adaLN gates are
+  // Linear(SiLU(cond)) of a nearest-x2 upsampled RNA level, i.e. constant over 2 x 2 voxel blocks.  gate_ls = log2(S), 0 = off
+  int gate_ls = 0;
 };
+
+// in-plane element offset of voxel (z, y, x) -> (z, y >> 1, x >> 1) of the half-resolution plane; ls = log2(S)
+__device__ __forceinline__ int half_res_off(int off8, int ls) {
+  const int v = off8 >> 3, S1 = (1 << ls) - 1;
+  const int x = v & S1, y = (v >> ls) & S1, z = v >> (2 * ls);
+  return (((z << (ls - 1)) + (y >> 1)) << (ls - 1) | (x >> 1)) << 3;
+}
 
 // XCD-aware workgroup id (cdna guide T1): the dispatcher deals consecutive blockIdx round-robin over the 8 XCDs
 // (private L2 each); this bijective remap hands every XCD one CONTIGUOUS run of logical tile ids, so the

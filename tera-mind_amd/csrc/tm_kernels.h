@@ -84,6 +84,7 @@ struct ConvLaunchH {
   int per_image = 1;
   TVH a2;
   int force_waves = 0;              // 0 = auto, 4 | 8 = workgroup form (tests / A-B; TM_CONV27_WAVES, TM_CONV1_WAVES)
+  int gate_half = 0;                // conv1 only: gate_h lives at S/2 and is read at (z, y >> 1, x >> 1) (S a power of two)
   // conv1 only: input = channel concat of nsrc (1..3) 16-bit CB8 tensors read in place, each optionally through the collage
   // remap of a (p1 x p2) source patch grid; `x` then only carries N, Z, H, W and the even-padded block count (x.p unused)
   int nsrc = 0;
@@ -117,7 +118,9 @@ struct PrepSrc {
   int Cb = 0;
   int collage = 0;
 };
-enum { RS_SAME = 0, RS_UP2 = 1, RS_DOWN2 = 2 };
+enum { RS_SAME = 0, RS_UP2 = 1, RS_DOWN2 = 2,
+       RS_PICK2 = 3 };   // output (z, y, x) at S <- source (z, 2y, 2x) at 2S (after the collage remap, if any): the distinct values of
+                         // a nearest-x2 upsampled tensor (16-bit block-input kernel only)
 enum { MOD_NONE = 0, MOD_IMAGE = 1, MOD_VOXEL = 2 };
 struct PrepLaunch {
   PrepSrc src[3];
@@ -133,6 +136,7 @@ struct PrepLaunch {
   long mod_stride = 0;              // MOD_IMAGE: floats per image row; MOD_VOXEL: nstride
   const uint16_t* mod_scale_h = nullptr;   // MOD_VOXEL with a bf16 CB8 modulation tensor (instead of mod_scale/shift)
   const uint16_t* mod_shift_h = nullptr;
+  int mod_half = 0;                 // MOD_VOXEL, 16-bit: the modulation tensors live at S/2 and are read at (z, y >> 1, x >> 1)
   int per_image = 1;                // output patches per image (n -> image index)
   int act = 0;                      // 1 = SiLU
   float* out = nullptr;

@@ -738,7 +738,9 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
     z = rem / (S * S); rem -= z * S * S;
     y = rem / S; x = rem - y * S;
   }
-  const int Ss = L.resample == RS_UP2 ? S / 2 : S;
+  // source plane size and the voxel's coordinates in it: as they are, nearest x2 (UP2), or every second voxel (PICK2);
+  // the collage remap (half a patch down / right, into the neighbouring encoder patch) is applied in source coordinates
+  const int Ss = L.resample == RS_UP2 ? S / 2 : (L.resample == RS_PICK2 ? 2 * S : S);
   const long splane = (long)Z * Ss * Ss * 8;               // elements per channel block of a source patch
   long soff[3];
 #pragma unroll
@@ -746,16 +748,17 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
     soff[k] = 0;
     if (k >= L.nsrc) continue;
     int ns = n, ys = y, xs = x;
+    if (L.resample == RS_UP2) { ys = y >> 1; xs = x >> 1; }
+    if (L.resample == RS_PICK2) { ys = 2 * y; xs = 2 * x; }
     if (L.src[k].collage) {
       const int q1 = L.p1 - 1, q2 = L.p2 - 1;
       const int bi = n / (q1 * q2);
       const int q = n - bi * q1 * q2;
       int i = q / q2, j = q - i * q2;
-      ys = y + S / 2; if (ys >= S) { ys -= S; i += 1; }
-      xs = x + S / 2; if (xs >= S) { xs -= S; j += 1; }
+      ys += Ss / 2; if (ys >= Ss) { ys -= Ss; i += 1; }
+      xs += Ss / 2; if (xs >= Ss) { xs -= Ss; j += 1; }
       ns = bi * L.p1 * L.p2 + i * L.p2 + j;
     }
-    if (L.resample == RS_UP2) { ys = y >> 1; xs = x >> 1; }
     soff[k] = (long)ns * L.src[k].nstride + ((long)(z * Ss + ys) * Ss + xs) * 8;
   }
   const int cb0 = L.src[0].Cb, cb01 = cb0 + ((L.nsrc > 1) ? L.src[1].Cb : 0);
@@ -812,7 +815,9 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
   const int img = n / L.per_image;
   uint16_t* const outp = L.out_h + (long)n * L.out_h_nstride + oin;
   uint16_t* const rawp = L.raw_h ? L.raw_h + (long)n * L.raw_h_nstride + oin : nullptr;
-  const long mo = (long)n * L.mod_stride + oin;
+  // per-voxel modulation tensors: the output geometry, or (mod_half) half its in-plane resolution
+  const long mplane = L.mod_half ? oplane >> 2 : oplane;
+  const long mo = (long)n * L.mod_stride + (L.mod_half ? ((long)(z * (S >> 1) + (y >> 1)) * (S >> 1) + (x >> 1)) * 8 : oin);
   constexpr int CH = 4;                                      // blocks per chunk: their modulation loads are issued together
 #pragma unroll
   for (int i0 = 0; i0 < NB; i0 += CH) {
@@ -822,8 +827,8 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
       for (int ii = 0; ii < CH; ++ii) {
         const int gb = g0 + WS * (i0 + ii);
         if (i0 + ii < NB && gb < cbtot) {
-          msc[ii] = *(const pu32x4*)(L.mod_scale_h + mo + (long)gb * oplane);
-          msh[ii] = *(const pu32x4*)(L.mod_shift_h + mo + (long)gb * oplane);
+          msc[ii] = *(const pu32x4*)(L.mod_scale_h + mo + (long)gb * mplane);
+          msh[ii] = *(const pu32x4*)(L.mod_shift_h + mo + (long)gb * mplane);
         }
       }
     }
@@ -906,10 +911,13 @@ static bool launch_prep_h16(const PrepLaunch& L, hipStream_t s, int variant) {
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s) {
   static const int env_form = getenv("TM_PREP_FORM") ? atoi(getenv("TM_PREP_FORM")) : 0;       // A/B timing only
   const int form = g_prep_variant ? g_prep_variant : env_form;
-  if (form != 1 && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample != RS_DOWN2 &&
+  const bool h16_only = L.resample == RS_PICK2 || L.mod_half;       // forms the generic kernel does not have
+  if ((form != 1 || h16_only) && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample != RS_DOWN2 &&
       (L.mod != MOD_VOXEL || L.mod_scale_h)) {
-    if (L.h_f16 ? launch_prep_h16<true>(L, s, form) : launch_prep_h16<false>(L, s, form)) return hipGetLastError();
+    if (L.h_f16 ? launch_prep_h16<true>(L, s, form == 1 ? 0 : form) : launch_prep_h16<false>(L, s, form == 1 ? 0 : form))
+      return hipGetLastError();
   }
+  if (h16_only) return hipErrorInvalidValue;
 
   PrepArgs pa; pa.L = L;
   const long vox = (long)L.N * L.Z * L.S * L.S;

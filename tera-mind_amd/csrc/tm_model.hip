@@ -802,11 +802,11 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
 
 static void run_conv1_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res, const TV* gate,
                         int flags, TVH* y_h = nullptr, const TVH* gate_h = nullptr, const TVH* res_h = nullptr,
-                        const std::vector<Src>* concat = nullptr) {
+                        const std::vector<Src>* concat = nullptr, bool gate_half = false) {
   if (cx.dry) return;
   ConvLaunchH L;
   L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.res = res; L.gate = gate; L.flags = flags;
-  L.gate_h = gate_h; L.res_h = res_h;
+  L.gate_h = gate_h; L.res_h = res_h; L.gate_half = gate_half ? 1 : 0;
   if (concat) {                       // x = th.cat(sources, 1) (+ to_collage) read in place; `x` carries the geometry only
     L.nsrc = (int)concat->size();
     for (int i = 0; i < L.nsrc; ++i) { L.xs[i] = as_h((*concat)[i].t); L.xs_collage[i] = (*concat)[i].collage ? 1 : 0; }
@@ -953,36 +953,52 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     // Activations that only feed a Linear, and the 7C modulation tensor (shift/scale/gate/cross-cond chunks), are
     // produced directly in bf16: the cross-cond chunk is the kv Linear's input as it stands.
     const int gbe = ((w.G + 7) / 8 + 1) / 2 * 2;
+    const int Tw = Z * (S / 2) * (S / 2);
+    const bool mfma_core = Tw == 128 || Tw == 64 || Tw == 32 || ((Tw == 256 || Tw == 512) && C <= 256);
+    // The conditioning side at HALF resolution.  cond is an RNA pyramid level, and every level leaves its stage through a
+    // nearest x2 Upsample (unet_ours.py:290-295, MBAblocks.py:472-479): it -- and with it SiLU(cond), the 7C adaLN modulation
+    // Linear(SiLU(cond)) (MBAblocks.py:463-466,487), the cross-cond chunk, k and v (no positional term, :551-556) -- is
+    // constant over aligned 2 x 2 voxel blocks, also after to_collage (a shift by S/2, even).  So these tensors are computed
+    // once per block of four voxels ([.., Z, S/2, S/2]: a quarter of the Linear work and of the bytes of the largest tensor
+    // of the block) and their consumers read entry (z, y >> 1, x >> 1).  Same numbers, bit for bit (TM_ATTN_HALF=0: the
+    // full-resolution form, for A/B timing and the equality test).
+    static const bool no_half = getenv("TM_ATTN_HALF") && atoi(getenv("TM_ATTN_HALF")) == 0;
+    const bool half = !no_half && (Tw == 128 || Tw == 64 || Tw == 32) && S >= 4 && !(S & (S - 1));
+    const int Sc = half ? S / 2 : S;
     // src16: the source is a 16-bit stream tensor (x, the RNA level); otherwise an fp32 scratch tensor
     auto prep_h = [&](const float* p, long ns, int Cbs, bool collage, const float* nw, const TVH* sc, const TVH* sh, int act,
-                      TVH dst, int Creal, bool src16 = true) {
+                      TVH dst, int Creal, bool src16 = true, int So = 0, int resample = RS_SAME) {
       if (cx.dry) return;
       PrepLaunch P;
       P.nsrc = 1;
       P.src_h = src16 ? 1 : 0;
       P.src[0].p = p; P.src[0].nstride = ns; P.src[0].Cb = Cbs; P.src[0].collage = collage ? 1 : 0;
-      P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = act; P.per_image = per_image;
+      P.N = N; P.Z = Z; P.S = So ? So : S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = act; P.per_image = per_image;
+      P.resample = resample;
       P.norm_w = nw; P.inv_c = 1.0f / (float)Creal;
-      if (sc) { P.mod = MOD_VOXEL; P.mod_scale_h = sc->p; P.mod_shift_h = sh->p; P.mod_stride = sc->nstride; }
+      if (sc) { P.mod = MOD_VOXEL; P.mod_scale_h = sc->p; P.mod_shift_h = sh->p; P.mod_stride = sc->nstride; P.mod_half = half ? 1 : 0; }
       P.out_h = dst.p; P.out_h_nstride = dst.nstride; P.pad_blocks = dst.Cb - Cbs; P.h_f16 = h_f16;
       cx.check(launch_prep(P, cx.s));
     };
-    TVH cact = cx.tensor_h(N, gbe, Z, S);
-    prep_h(cond.t.p, cond.t.nstride, cond.t.Cb, cond.collage, nullptr, nullptr, nullptr, 1, cact, w.G);
-    TVH mod = cx.tensor_h(N, 7 * cb, Z, S);
-    TV mod_geom = x; mod_geom.Cb = 7 * cb; mod_geom.C = 7 * C; mod_geom.p = nullptr; mod_geom.nstride = (long)7 * cb * x.plane();
+    const long cplane = (long)Z * Sc * Sc * 8;                     // elements per channel block on the conditioning side
+    TVH cact = cx.tensor_h(N, gbe, Z, Sc);
+    prep_h(cond.t.p, cond.t.nstride, cond.t.Cb, cond.collage, nullptr, nullptr, nullptr, 1, cact, w.G, true, Sc,
+           half ? RS_PICK2 : RS_SAME);
+    TVH mod = cx.tensor_h(N, 7 * cb, Z, Sc);
+    TV mod_geom = x; mod_geom.H = Sc; mod_geom.W = Sc; mod_geom.Cb = 7 * cb; mod_geom.C = 7 * C; mod_geom.p = nullptr;
+    mod_geom.nstride = (long)7 * cb * cplane;
     run_conv1_h(cx, cact, w.adah, w.ada, mod_geom, nullptr, nullptr, 0, &mod);
     // chunk order (MBAblocks.py:487): shift_msa, scale_msa, gate_msa, crss_cnd, shift_mlp, scale_mlp, gate_mlp
     TVH sh_a = mod.blocks(0 * cb, cb), sc_a = mod.blocks(1 * cb, cb), g_a = mod.blocks(2 * cb, cb);
     TVH crs = mod.blocks(3 * cb, cb), sh_m = mod.blocks(4 * cb, cb), sc_m = mod.blocks(5 * cb, cb), g_m = mod.blocks(6 * cb, cb);
     TVH xa = cx.tensor_h(N, cb, Z, S), oh = cx.tensor_h(N, cb, Z, S);
     prep_h(x.p, x.nstride, x.Cb, false, w.n1, &sc_a, &sh_a, 0, xa, C);
-    const int Tw = Z * (S / 2) * (S / 2);
-    if (Tw == 128 || Tw == 64 || Tw == 32 || ((Tw == 256 || Tw == 512) && C <= 256)) {
+    if (mfma_core) {
       // q, k, v leave their Linears as 16-bit (the attention core's MFMA operands); softmax and accumulation are fp32
-      TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, S);
+      TVH q = cx.tensor_h(N, cb, Z, S), kv = cx.tensor_h(N, 2 * cb, Z, Sc);
       TV q_geom = x; q_geom.p = nullptr;
-      TV kv_geom = x; kv_geom.Cb = 2 * cb; kv_geom.C = 2 * C; kv_geom.p = nullptr; kv_geom.nstride = (long)2 * cb * x.plane();
+      TV kv_geom = x; kv_geom.H = Sc; kv_geom.W = Sc; kv_geom.Cb = 2 * cb; kv_geom.C = 2 * C; kv_geom.p = nullptr;
+      kv_geom.nstride = (long)2 * cb * cplane;
       q_geom.nstride = (long)cb * x.plane();
       run_conv1_h(cx, xa, w.qh, w.q, q_geom, nullptr, nullptr, 0, &q);
       run_conv1_h(cx, crs, w.kvh, w.kv, kv_geom, nullptr, nullptr, 0, &kv);
@@ -998,12 +1014,12 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     }
     // x <- x + gate * Linear(.): the 16-bit stream tensor is updated in place (each element is read and written by one lane)
     TVH xh = as_h(x);
-    run_conv1_h(cx, oh, w.projh, w.proj, x, nullptr, nullptr, 0, &xh, &g_a, &xh);
+    run_conv1_h(cx, oh, w.projh, w.proj, x, nullptr, nullptr, 0, &xh, &g_a, &xh, nullptr, half);
     prep_h(x.p, x.nstride, x.Cb, false, w.n2, &sc_m, &sh_m, 0, xa, C);
     TVH h1 = cx.tensor_h(N, 4 * cb, Z, S);
     TV h1_geom = x; h1_geom.Cb = 4 * cb; h1_geom.C = 4 * C; h1_geom.p = nullptr; h1_geom.nstride = (long)4 * cb * x.plane();
     run_conv1_h(cx, xa, w.fc1h, w.fc1, h1_geom, nullptr, nullptr, EPI_GELU, &h1);
-    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, nullptr, nullptr, 0, &xh, &g_m, &xh);
+    run_conv1_h(cx, h1, w.fc2h, w.fc2, x, nullptr, nullptr, 0, &xh, &g_m, &xh, nullptr, half);
     cx.top = mark;
     return;
   }
