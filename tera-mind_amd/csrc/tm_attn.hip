@@ -559,7 +559,10 @@ struct WinArgs {
   int C, Z, S;
   long plane;
   uint16_t* o_h; long o_h_ns;
+  int kv_ls;      // != 0: k / v live at half the in-plane resolution (token (z, y, x) reads (z, y >> 1, x >> 1)); = log2(S)
 };
+// token offset inside a k / v patch, and the k / v channel-block plane, from the q-geometry token offset
+#define TM_KVOFF(o) (a.kv_ls ? half_res_off((o), a.kv_ls) : (o))
 
 template <int T>
 __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
@@ -588,13 +591,15 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
   const float* qb = a.q + (long)n * a.q_ns;
   const float* kb = a.k + (long)n * a.k_ns;
   const float* vb = a.v + (long)n * a.v_ns;
+  const long kvp = a.kv_ls ? a.plane >> 2 : a.plane;             // channel-block plane of k / v
   if (tid < 2 * T) {
     const bool isq = tid < T;
     const int t = isq ? tid : tid - T;
-    const float* p = (isq ? qb : kb) + tokoff[t];
+    const float* p = isq ? qb + tokoff[t] : kb + TM_KVOFF(tokoff[t]);
+    const long pp = isq ? a.plane : kvp;
     float ss = 0.f;
     for (int cb = 0; cb < C / 8; ++cb) {
-      const f32x4 a0 = *(const f32x4*)(p + (long)cb * a.plane), a1 = *(const f32x4*)(p + (long)cb * a.plane + 4);
+      const f32x4 a0 = *(const f32x4*)(p + (long)cb * pp), a1 = *(const f32x4*)(p + (long)cb * pp + 4);
       ss += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] + a1[0] * a1[0] + a1[1] * a1[1] +
             a1[2] * a1[2] + a1[3] * a1[3];
     }
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
       const int t = (it >> 1) % T;
       const bool isq = (it >> 1) < T;
       const int cb = c0 / 8 + cbi;
-      const float* p = (isq ? qb : kb) + tokoff[t] + (long)cb * a.plane;
+      const float* p = isq ? qb + tokoff[t] + (long)cb * a.plane : kb + TM_KVOFF(tokoff[t]) + (long)cb * kvp;
       const f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
       const float r = isq ? rq[t] : rk[t];
       const float* nw = (isq ? a.qw : a.kw) + cb * 8;
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
     for (int u0 = 0; u0 < T; u0 += 16) {
       {
         const int uu = tid >> 4, cbi = tid & 15;
-        const float* p = vb + tokoff[u0 + uu] + (long)(c0 / 8 + cbi) * a.plane;
+        const float* p = vb + TM_KVOFF(tokoff[u0 + uu]) + (long)(c0 / 8 + cbi) * kvp;
         *(f32x4*)(vs + uu * 128 + cbi * 8) = *(const f32x4*)p;
         *(f32x4*)(vs + uu * 128 + cbi * 8 + 4) = *(const f32x4*)(p + 4);
       }
@@ -742,13 +747,15 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
   const float* qb = a.q + (long)n * a.q_ns;
   const float* kb = a.k + (long)n * a.k_ns;
   const float* vb = a.v + (long)n * a.v_ns;
+  const long kvp = a.kv_ls ? a.plane >> 2 : a.plane;             // channel-block plane of k / v
   {
     const bool isq = tid < T;
     const int t = isq ? tid : tid - T;
-    const float* p = (isq ? qb : kb) + tokoff[t];
+    const float* p = isq ? qb + tokoff[t] : kb + TM_KVOFF(tokoff[t]);
+    const long pp = isq ? a.plane : kvp;
     float ss = 0.f;
     for (int cb = 0; cb < C / 8; ++cb) {
-      const f32x4 a0 = *(const f32x4*)(p + (long)cb * a.plane), a1 = *(const f32x4*)(p + (long)cb * a.plane + 4);
+      const f32x4 a0 = *(const f32x4*)(p + (long)cb * pp), a1 = *(const f32x4*)(p + (long)cb * pp + 4);
       ss += a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3] + a1[0] * a1[0] + a1[1] * a1[1] +
             a1[2] * a1[2] + a1[3] * a1[3];
     }
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
   const float* qp = qb + tokoff[wv * 32 + i32] + 4 * h;
   const float* kp[4];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) kp[ct] = kb + tokoff[ct * 32 + i32] + 4 * h;
+  for (int ct = 0; ct < 4; ++ct) kp[ct] = kb + TM_KVOFF(tokoff[ct * 32 + i32]) + 4 * h;
   // fragments of channel block cb+1 are in flight while block cb's 16 MFMAs issue (one workgroup per CU: nothing
   // else would hide the L2 round trip)
   f32x4 qn = *(const f32x4*)qp, kn[4];
@@ -779,10 +786,10 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) kf[ct] = kn[ct] * wf;
     if (cb + 1 < C / 8) {
-      const long po = (long)(cb + 1) * a.plane;
+      const long po = (long)(cb + 1) * a.plane, pk = (long)(cb + 1) * kvp;
       qn = *(const f32x4*)(qp + po);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const f32x4*)(kp[ct] + po);
+      for (int ct = 0; ct < 4; ++ct) kn[ct] = *(const f32x4*)(kp[ct] + pk);
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -819,10 +826,10 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
   // V chunk staging: thread owns items (u, cbi) = (tid & 127, tid >> 7) and (tid & 127, 2 + (tid >> 7)); the next
   // chunk's two 32-byte pieces are loaded into registers before the current chunk's MFMAs
   const int su = tid & (T - 1), scb = tid >> 7;
-  const float* vsrc = vb + tokoff[su] + (long)scb * a.plane;
+  const float* vsrc = vb + TM_KVOFF(tokoff[su]) + (long)scb * kvp;
   f32x4 vr[4];
   vr[0] = *(const f32x4*)vsrc; vr[1] = *(const f32x4*)(vsrc + 4);
-  vr[2] = *(const f32x4*)(vsrc + 2 * a.plane); vr[3] = *(const f32x4*)(vsrc + 2 * a.plane + 4);
+  vr[2] = *(const f32x4*)(vsrc + 2 * kvp); vr[3] = *(const f32x4*)(vsrc + 2 * kvp + 4);
   for (int c0 = 0; c0 < C; c0 += 32) {
     __syncthreads();                                               // Vt free (and, first time, P complete)
 #pragma unroll
@@ -833,9 +840,9 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(WinArgs a) {
       d[4 * PS] = v1[0]; d[5 * PS] = v1[1]; d[6 * PS] = v1[2]; d[7 * PS] = v1[3];
     }
     if (c0 + 32 < C) {
-      const float* p = vsrc + (long)((c0 + 32) / 8) * a.plane;
+      const float* p = vsrc + (long)((c0 + 32) / 8) * kvp;
       vr[0] = *(const f32x4*)p; vr[1] = *(const f32x4*)(p + 4);
-      vr[2] = *(const f32x4*)(p + 2 * a.plane); vr[3] = *(const f32x4*)(p + 2 * a.plane + 4);
+      vr[2] = *(const f32x4*)(p + 2 * kvp); vr[3] = *(const f32x4*)(p + 2 * kvp + 4);
     }
     __syncthreads();
     f32x16 oc;
@@ -1175,6 +1182,14 @@ hipError_t launch_window_attn(const TV& q, const TV& k, const TV& v, const float
   a.C = q.Cb * 8; a.Z = q.Z; a.S = q.H; a.plane = q.plane();
   if (a.C % 8 || q.H != q.W || (q.H & 1)) return hipErrorInvalidValue;
   const int T = q.Z * (q.H / 2) * (q.H / 2);
+  a.kv_ls = 0;
+  if (k.H != q.H) {     // k / v at half the in-plane resolution: the T = 128 MFMA and the T = 32 kernels only, S a power of two
+    int ls = 0;
+    while ((1 << ls) < q.H) ++ls;
+    if (k.H * 2 != q.H || v.H != k.H || (1 << ls) != q.H || ls < 2 || a.C % 128 || !((T == 128 && a.C <= 512) || T == 32))
+      return hipErrorInvalidValue;
+    a.kv_ls = ls;
+  }
   if ((T == 256 || T == 512) && a.C <= 256 && !o_h) {   // long windows: key-blocked fp32 MFMA form
     const size_t lds = ((size_t)(128 + 32) * WinLongLds::PS + 128 + 2 * T + a.C) * sizeof(float);
 #define TM_LAUNCHWL(T_)                                                                                              \

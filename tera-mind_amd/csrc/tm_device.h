@@ -109,7 +109,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
         ok[g][mt] = cob < a.Cob && ooff[mt] >= 0;
         const long pl = ok[g][mt] ? (long)cob * a.y_plane + ooff[mt] + 4 * h : 0;
         if (a.res) rv[g][mt] = *(const f32x4*)(a.res + (ok[g][mt] ? (long)on[mt] * a.res_nstride : 0) + pl);
-        if (a.gate) gv[g][mt] = *(const f32x4*)(a.gate + (ok[g][mt] ? (long)on[mt] * a.gate_nstride : 0) + pl);
+        if (a.gate) {
+          const long gpl = !a.gate_ls ? pl : (ok[g][mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.gate_ls) + 4 * h : 0);
+          gv[g][mt] = *(const f32x4*)(a.gate + (ok[g][mt] ? (long)on[mt] * a.gate_nstride : 0) + gpl);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);

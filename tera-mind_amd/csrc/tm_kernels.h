@@ -47,6 +47,7 @@ struct ConvLaunch {
   const TV* gate = nullptr;  // optional gate: y = res + gate * (conv + bias)
   int flags = 0;
   int tile_variant = 0;  // 0 auto, 1 = 128-voxel blocks, 2 = 256-voxel blocks
+  int gate_half = 0;     // taps == 1 only: `gate` lives at S/2 and is read at (z, y >> 1, x >> 1) (S a power of two)
   int zmode = ZM_PAD1;   // ignored for taps == 1
 };
 hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s);
@@ -119,8 +120,8 @@ struct PrepSrc {
   int collage = 0;
 };
 enum { RS_SAME = 0, RS_UP2 = 1, RS_DOWN2 = 2,
-       RS_PICK2 = 3 };   // output (z, y, x) at S <- source (z, 2y, 2x) at 2S (after the collage remap, if any): the distinct values of
-                         // a nearest-x2 upsampled tensor (16-bit block-input kernel only)
+       RS_PICK2 = 3 };   // output (z, y, x) at S <- source (z, 2y, 2x) at 2S (then the collage remap, if any): the distinct values of
+                         // a nearest-x2 upsampled tensor
 enum { MOD_NONE = 0, MOD_IMAGE = 1, MOD_VOXEL = 2 };
 struct PrepLaunch {
   PrepSrc src[3];
@@ -136,7 +137,7 @@ struct PrepLaunch {
   long mod_stride = 0;              // MOD_IMAGE: floats per image row; MOD_VOXEL: nstride
   const uint16_t* mod_scale_h = nullptr;   // MOD_VOXEL with a bf16 CB8 modulation tensor (instead of mod_scale/shift)
   const uint16_t* mod_shift_h = nullptr;
-  int mod_half = 0;                 // MOD_VOXEL, 16-bit: the modulation tensors live at S/2 and are read at (z, y >> 1, x >> 1)
+  int mod_half = 0;                 // MOD_VOXEL: the modulation tensors live at S/2 and are read at (z, y >> 1, x >> 1)
   int per_image = 1;                // output patches per image (n -> image index)
   int act = 0;                      // 1 = SiLU
   float* out = nullptr;

@@ -344,6 +344,12 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
   a.y = L.y.p; a.y_nstride = L.y.nstride; a.y_plane = L.y.plane(); a.Cob = L.y.Cb;
   a.res = L.res ? L.res->p : nullptr; a.res_nstride = L.res ? L.res->nstride : 0;
   a.gate = L.gate ? L.gate->p : nullptr; a.gate_nstride = L.gate ? L.gate->nstride : 0;
+  if (L.gate_half) {
+    int ls = 0;
+    while ((1 << ls) < L.y.H) ++ls;
+    if (!L.gate || L.w.taps != 1 || (1 << ls) != L.y.H || L.y.H != L.y.W || ls < 1) return hipErrorInvalidValue;
+    a.gate_ls = ls;
+  }
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.w.Cbi; a.ntile = L.w.ntile; a.flags = L.flags;
   if (L.x.Cb != L.w.Cbi || L.x.H != L.x.W) return hipErrorInvalidValue;
   if (L.y.Cb > L.w.ntile * 8 || L.y.N != L.x.N) return hipErrorInvalidValue;
@@ -467,22 +473,24 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
     if (k >= L.nsrc) { splane[k] = 0; continue; }
     int Ss = S;
     if (L.resample == RS_UP2) Ss = S / 2;
-    if (L.resample == RS_DOWN2) Ss = S * 2;
+    if (L.resample == RS_DOWN2 || L.resample == RS_PICK2) Ss = S * 2;
     splane[k] = (long)Z * Ss * Ss * 8;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
+      // the voxel's coordinates in the source plane, then (collage) half a source patch down / right into the neighbour
       int ns = n, ys = y, xs = x;
+      if (L.resample == RS_UP2) { ys = y >> 1; xs = x >> 1; }
+      if (L.resample == RS_DOWN2) { ys = 2 * y + (sub >> 1); xs = 2 * x + (sub & 1); }
+      if (L.resample == RS_PICK2) { ys = 2 * y; xs = 2 * x; }
       if (L.src[k].collage) {
         const int q1 = L.p1 - 1, q2 = L.p2 - 1;
         const int bi = n / (q1 * q2);
         const int q = n - bi * q1 * q2;
         int i = q / q2, j = q - i * q2;
-        ys = y + S / 2; if (ys >= S) { ys -= S; i += 1; }
-        xs = x + S / 2; if (xs >= S) { xs -= S; j += 1; }
+        ys += Ss / 2; if (ys >= Ss) { ys -= Ss; i += 1; }
+        xs += Ss / 2; if (xs >= Ss) { xs -= Ss; j += 1; }
         ns = bi * L.p1 * L.p2 + i * L.p2 + j;
       }
-      if (L.resample == RS_UP2) { ys = y >> 1; xs = x >> 1; }
-      if (L.resample == RS_DOWN2) { ys = 2 * y + (sub >> 1); xs = 2 * x + (sub & 1); }
       soff[k][sub] = (long)ns * L.src[k].nstride + ((long)(z * Ss + ys) * Ss + xs) * 8;
     }
   }
@@ -576,7 +584,9 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         sh[j] = L.mod_shift[(long)img * L.mod_stride + gb * 8 + j];
       }
     } else if (L.mod == MOD_VOXEL) {
-      const long mo = (long)n * L.mod_stride + (long)gb * oplane + oin;
+      const long mo = !L.mod_half ? (long)n * L.mod_stride + (long)gb * oplane + oin
+                                  : (long)n * L.mod_stride + (long)gb * (oplane >> 2) +
+                                        ((long)(z * (S >> 1) + (y >> 1)) * (S >> 1) + (x >> 1)) * 8;
       if (L.mod_scale_h) {
         if (L.h_f16) {
           typedef _Float16 f16x8_m __attribute__((ext_vector_type(8)));
@@ -911,13 +921,10 @@ static bool launch_prep_h16(const PrepLaunch& L, hipStream_t s, int variant) {
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s) {
   static const int env_form = getenv("TM_PREP_FORM") ? atoi(getenv("TM_PREP_FORM")) : 0;       // A/B timing only
   const int form = g_prep_variant ? g_prep_variant : env_form;
-  const bool h16_only = L.resample == RS_PICK2 || L.mod_half;       // forms the generic kernel does not have
-  if ((form != 1 || h16_only) && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample != RS_DOWN2 &&
+  if (form != 1 && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample != RS_DOWN2 &&
       (L.mod != MOD_VOXEL || L.mod_scale_h)) {
-    if (L.h_f16 ? launch_prep_h16<true>(L, s, form == 1 ? 0 : form) : launch_prep_h16<false>(L, s, form == 1 ? 0 : form))
-      return hipGetLastError();
+    if (L.h_f16 ? launch_prep_h16<true>(L, s, form) : launch_prep_h16<false>(L, s, form)) return hipGetLastError();
   }
-  if (h16_only) return hipErrorInvalidValue;
 
   PrepArgs pa; pa.L = L;
   const long vox = (long)L.N * L.Z * L.S * L.S;

@@ -741,10 +741,10 @@ static void dump_tv(Ctx& cx, const std::string& name, const TV& t_in) {
 }
 
 static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags,
-                     int cin_real = 0, int zmode = ZM_PAD1) {
+                     int cin_real = 0, int zmode = ZM_PAD1, bool gate_half = false) {
   if (cx.dry) return;
   ConvLaunch L;
-  L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags; L.zmode = zmode;
+  L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags; L.zmode = zmode; L.gate_half = gate_half ? 1 : 0;
   tm_model* m = cx.m;
   const bool prof = m->prof_on && (w.taps == 27 || (m->z == 1 && w.taps == 9)) && zmode == ZM_PAD1;
   if (prof) {
@@ -1023,19 +1023,25 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     cx.top = mark;
     return;
   }
-  // SiLU(cond) (adaLN_modulation[0], MBAblocks.py:464): reuse the activated RNA level when the
-  // cond is not re-tiled (encoder / middle), gather + activate for the collage decoder
-  TV cact = cond_act ? *cond_act : cx.tensor(N, (w.G + 7) / 8 * 8, Z, S);
-  if (!cx.dry && !cond_act) {
+  // fp32: the same structure.  The conditioning side (SiLU(cond), the 7C modulation, k, v) at half resolution where the
+  // attention core has the k / v half-resolution read (T = 128 MFMA and T = 32 kernels, C a multiple of 128), see above;
+  // otherwise at full resolution, reusing the activated RNA level when the cond is not re-tiled (encoder / middle).
+  const int Tw = Z * (S / 2) * (S / 2);
+  static const bool no_half32 = getenv("TM_ATTN_HALF") && atoi(getenv("TM_ATTN_HALF")) == 0;
+  const bool half = !no_half32 && S >= 4 && !(S & (S - 1)) && C % 128 == 0 && ((Tw == 128 && C <= 512) || Tw == 32);
+  const int Sc = half ? S / 2 : S;
+  TV cact = (cond_act && !half) ? *cond_act : cx.tensor(N, (w.G + 7) / 8 * 8, Z, Sc);
+  if (!cx.dry && (half || !cond_act)) {
     PrepLaunch P;
     P.nsrc = 1;
     P.src[0].p = cond.t.p; P.src[0].nstride = cond.t.nstride; P.src[0].Cb = cond.t.Cb;
     P.src[0].collage = cond.collage ? 1 : 0;
-    P.N = N; P.Z = Z; P.S = S; P.p1 = cx.p1; P.p2 = cx.p2; P.act = 1; P.per_image = per_image;
+    P.resample = half ? RS_PICK2 : RS_SAME;
+    P.N = N; P.Z = Z; P.S = Sc; P.p1 = cx.p1; P.p2 = cx.p2; P.act = 1; P.per_image = per_image;
     P.out = cact.p; P.out_nstride = cact.nstride;
     cx.check(launch_prep(P, cx.s));
   }
-  TV mod = cx.tensor(N, 7 * C, Z, S);
+  TV mod = cx.tensor(N, 7 * C, Z, Sc);
   run_conv(cx, cact, w.ada, mod, nullptr, nullptr, 0);
   // chunk order (MBAblocks.py:487): shift_msa, scale_msa, gate_msa, crss_cnd, shift_mlp, scale_mlp, gate_mlp
   TV sh_a = mod.blocks(0 * cb, cb), sc_a = mod.blocks(1 * cb, cb), g_a = mod.blocks(2 * cb, cb);
@@ -1047,20 +1053,20 @@ static void attn_block(Ctx& cx, const AttnW& w, TV x, const Src& cond, int per_i
     P.nsrc = 1;
     P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
     P.N = N; P.Z = Z; P.S = S; P.norm_w = nw; P.inv_c = 1.0f / (float)C; P.per_image = per_image;
-    P.mod = MOD_VOXEL; P.mod_scale = sc.p; P.mod_shift = sh.p; P.mod_stride = mod.nstride;
+    P.mod = MOD_VOXEL; P.mod_scale = sc.p; P.mod_shift = sh.p; P.mod_stride = mod.nstride; P.mod_half = half ? 1 : 0;
     P.out = dst.p; P.out_nstride = dst.nstride;
     cx.check(launch_prep(P, cx.s));
   };
   modulate(w.n1, sc_a, sh_a, xa);
-  TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, S), o = cx.tensor(N, C, Z, S);
+  TV q = cx.tensor(N, C, Z, S), kv = cx.tensor(N, 2 * C, Z, Sc), o = cx.tensor(N, C, Z, S);
   run_conv(cx, xa, w.q, q, nullptr, nullptr, 0);
   run_conv(cx, crs, w.kv, kv, nullptr, nullptr, 0);
   if (!cx.dry) cx.check(launch_window_attn(q, kv.blocks(0, cb), kv.blocks(cb, cb), w.qn, w.kn, o, cx.s));
-  run_conv(cx, o, w.proj, x, &x, &g_a, 0);
+  run_conv(cx, o, w.proj, x, &x, &g_a, 0, 0, ZM_PAD1, half);
   modulate(w.n2, sc_m, sh_m, xa);
   TV h1 = cx.tensor(N, 4 * C, Z, S);
   run_conv(cx, xa, w.fc1, h1, nullptr, nullptr, EPI_GELU);
-  run_conv(cx, h1, w.fc2, x, &x, &g_m, 0);
+  run_conv(cx, h1, w.fc2, x, &x, &g_m, 0, 0, ZM_PAD1, half);
   cx.top = mark;
 }
 

@@ -233,9 +233,9 @@ def test_precomputed_rna_pyramid_is_bit_identical(dtype):
         m(x=x[:9].to(DEV), t=t[:1].to(DEV), rna=pyr, imgs=torch.zeros(1, 4, 128, 128), patch_size=64)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_half_resolution_conditioning_is_bit_identical(dtype, tmp_path):
-    """The 16-bit AttnBlock computes SiLU(cond), the 7C adaLN modulation, the cross-cond chunk, k and v once per aligned
+    """The AttnBlock computes SiLU(cond), the 7C adaLN modulation, the cross-cond chunk, k and v once per aligned
     2 x 2 voxel block (cond is a nearest-x2 upsampled RNA level: unet_ours.py:290-295, MBAblocks.py:463-466,472-479,487) and
     reads them at (z, y >> 1, x >> 1).  TM_ATTN_HALF=0 switches the full-resolution form back on (read once per process,
     hence the child): both must agree bit for bit, through the plain encoder blocks and the collage decoder."""
