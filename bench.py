@@ -141,7 +141,7 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     """The row-sharded ROI sweep (strong scaling).  Returns the `sweep` result dict (rank 0 fills the JSON from it)."""
     import torch
     from teramind_amd import launch
-    from teramind_amd.brain import device_gene_provider
+    from teramind_amd.brain import consistent_gene_provider, device_gene_provider
     from teramind_amd.config import PathConfig
     from teramind_amd.diffusion import SpacedDiffusionBeatGans
     from teramind_amd.unet import BeatGANsUNetModel
@@ -150,7 +150,9 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
     T = 15                                                    # test_brn default: 15-step DDIM (test_brn.py:329-330)
     smp = SpacedDiffusionBeatGans(T, "ddim")
-    genes = device_gene_provider(cfg, dev)
+    # share_halo needs gene tiles that agree where they overlap (as tiles cut from one gene map do): the block-seeded provider
+    share = bool(args.sweep_share_halo) and args.sweep_batch_tiles > 1
+    genes = consistent_gene_provider(cfg, dev) if share else device_gene_provider(cfg, dev)
 
     def on_step(sw, s):
         if rank == 0:
@@ -159,7 +161,8 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     # warm-up steps run unprofiled; the hipEvent brackets cover exactly the timed steps
     res = launch.run_sweep(cfg, smp, model, genes, hnm=args.sweep_hnm, wnm=args.sweep_wnm, total_epochs=T, steps=steps,
                            warmup=warmup, device=dev, batch_tiles=args.sweep_batch_tiles, init="device", state="fp16",
-                           on_step=on_step, after_warmup=lambda: model.profile(True))
+                           on_step=on_step, after_warmup=lambda: model.profile(True), share_halo=share,
+                           prefetch_genes=not share)
     prof = model.profile_collect()
     model.profile(False)
     st = res["sweep"].local_state()
@@ -180,6 +183,10 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
                         f"16 interior patches, P=4) per diffusion step, DDIM-15 schedule, {args.sweep_dtype} UNet arithmetic, one "
                         f"float16 state canvas per rank, tile rows split over {world} rank(s)"),
            "tiles": tiles, "steps": steps, "warmup": warmup, "s_per_step": round(res["dt"] / steps, 4),
+           "tiles_per_model_call": args.sweep_batch_tiles,
+           # one window per call: the patch columns neighbouring tiles share go through the encoder once (bit-identical for
+           # gene tiles that agree where they overlap)
+           "share_halo": share,
            "s_per_tile_step_per_gpu": round(res["dt"] / steps / max(1, -(-args.sweep_hnm // world) * args.sweep_wnm), 5),
            "world_size_rccl": res["world"], "backend": res["backend"],
            "exchange_ms_per_step": round(res["exchange_ms_per_step"], 3),
@@ -331,7 +338,9 @@ def main():
     ap.add_argument("--sweep-wnm", type=int, default=8)
     ap.add_argument("--sweep-steps", type=int, default=2, help="timed diffusion steps of the appended sweep (1 warm-up step)")
     ap.add_argument("--sweep-dtype", choices=["bf16", "f16", "f32"], default="bf16")
-    ap.add_argument("--sweep-batch-tiles", type=int, default=1)
+    ap.add_argument("--sweep-batch-tiles", type=int, default=8, help="tiles of a tile row per model call")
+    ap.add_argument("--sweep-share-halo", type=int, default=1,
+                    help="1: the tiles of a call form one window (shared encoder patch columns computed once); 0: stacked tiles")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (checks the plumbing, measures nothing)")
     args = ap.parse_args()

@@ -36,7 +36,7 @@ class TileSweep:
                  hst: int = 256, wst: int = 256, hnm: int = 32, wnm: int = 32, total_epochs: int = 15,
                  total_slc: int = 50, device="cpu", rank: int = 0, world: int = 1, batch_tiles: int = 1,
                  group=None, init: str = "reference", noise_provider: Optional[Callable] = None,
-                 state: str = "fp32x2"):
+                 state: str = "fp32x2", share_halo: bool = False):
         """hst/wst/hnm/wnm/total_epochs mirror the test_brn CLI (test_brn.py:302-334).
         gene_provider(row, col) -> dense [20, 20, (total_slc + 2*zpad) * 500] gene tile (already
         block-summed and z-padded like MBADataset_tst._getgene/_pad_gn) for ABSOLUTE tile
@@ -49,7 +49,17 @@ class TileSweep:
                canvas is lossless from step 1 on; step 0's float32 noise is never stored -- a three-row band of
                noise tiles is regenerated from the LCG seeds as the sweep moves down -- and new tile rows are
                committed one row late, once the row below has consumed the old halo.  Results are
-               bit-identical to 'fp32x2'."""
+               bit-identical to 'fp32x2'.
+        share_halo: the tiles of one model call (`batch_tiles` consecutive tiles of a tile row) are handed over as ONE
+               window of 256 * k + 64 columns, i.e. a (P + 1) x (k P + 1) encoder patch grid instead of k grids of
+               (P + 1) x (P + 1): the reference runs the encoder twice on every patch column two neighbouring tiles
+               share (the right halo of one is the left interior edge of the next, on the same 64-px grid), here it
+               runs once -- 165 instead of 200 encoder patches per z-chunk at k = 8.  Encoder patches are computed in
+               isolation (SURVEY 8e "global equivalence"), so the result is the same bit for bit PROVIDED the gene
+               tiles agree where they overlap (they are cut with overlap from one gene map,
+               utils/MBADataset_tst.py:65-91; `consistent_gene_provider` has that property, a per-tile seeded
+               provider does not).  The window's genes: every tile's own 16 interior cell columns, the outer halo
+               columns from the first / last tile."""
         if state not in ("fp32x2", "fp16"):
             raise ValueError(f"state {state!r}")
         self.state = state
@@ -65,6 +75,7 @@ class TileSweep:
         self.chn = total_slc * conf.n_stain
         self.dev, self.rank, self.world, self.group = torch.device(device), rank, world, group
         self.batch_tiles, self.init, self.noise_provider = batch_tiles, init, noise_provider
+        self.share_halo = bool(share_halo)
         self.r0, self.r1 = tiles.row_block_partition(hnm, world)[rank]
         self.nrows = self.r1 - self.r0
         H = self.nrows * tiles.TILE + 2 * PAD
@@ -194,9 +205,44 @@ class TileSweep:
             return self._strip(lr)[:, :, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)
         return self.cur[:, y:y + tiles.TILE + 2 * PAD, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)     # 'h w c'
 
+    def _run_row_window(self, lr: int, c0: int, k: int, epoch: int):
+        """share_halo: tiles (lr, c0 .. c0 + k - 1) as one window -> [C, 256, 256 k] float32 result."""
+        conf = self.conf
+        x0, wpx = c0 * tiles.TILE, k * tiles.TILE + 2 * PAD
+        if self.state == "fp16":
+            win = self._strip(lr)[:, :, x0:x0 + wpx]
+        else:
+            y = lr * tiles.TILE
+            win = self.cur[:, y:y + tiles.TILE + 2 * PAD, x0:x0 + wpx]
+        blk = conf.patch_size // conf.gn_sz                                   # pixels per gene cell
+        hc, ic = PAD // blk, tiles.TILE // blk                               # halo / interior cells per tile side
+        gts = [self.gene(self.row0 + self.r0 + lr, self.col0 + c0 + j).to(self.dev) for j in range(k)]
+        cols = [gts[0][:, :hc]] + [g[:, hc:hc + ic] for g in gts] + [gts[-1][:, hc + ic:]]
+        rna_hwc = torch.cat(cols, dim=1)[None]
+        x, rna, shape = tiles.run_batch_inputs(win.permute(1, 2, 0)[None], rna_hwc, conf.patch_size, conf.gn_sz,
+                                               self.total_slc, conf.rna_slc)
+        out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
+                                  patch_size=conf.patch_size, idx=self.T - epoch - 1, model_kwargs=None)
+        return tiles.regroup_output(out, 1, self.n_stain)[0]
+
     def run_batch(self, tile_list, epoch: int):
         """Tester._run_batch (test_brn.py:174-226) for a list of (local_row, col) tiles."""
         conf = self.conf
+        if self.share_halo and len(tile_list) > 1:
+            lr, c0 = tile_list[0]
+            if [(lr, c0 + j) for j in range(len(tile_list))] != list(tile_list):
+                raise ValueError("share_halo: the tiles of a call must be consecutive tiles of one row")
+            out = self._run_row_window(lr, c0, len(tile_list), epoch)
+            x0, x1 = c0 * tiles.TILE, (c0 + len(tile_list)) * tiles.TILE
+            if self.state == "fp16":
+                if lr not in self._pending:
+                    self._pending[lr] = torch.empty((self.chn, tiles.TILE, self.wnm * tiles.TILE), dtype=torch.float16,
+                                                    device=self.dev)
+                self._pending[lr][:, :, x0:x1].copy_(out.half())              # test_brn.py:222
+            else:
+                y = PAD + lr * tiles.TILE
+                self.nxt[:, y:y + tiles.TILE, PAD + x0:PAD + x1].copy_(out.half().float())
+            return
         tile_hwc = torch.stack([self._window(lr, c) for lr, c in tile_list])
         rna_hwc = torch.stack([self.gene(self.row0 + self.r0 + lr, self.col0 + c).to(self.dev) for lr, c in tile_list])
         x, rna, shape = tiles.run_batch_inputs(tile_hwc, rna_hwc, conf.patch_size, conf.gn_sz, self.total_slc, conf.rna_slc)
@@ -217,8 +263,12 @@ class TileSweep:
 
     def step(self):
         todo = [(lr, c) for lr in range(self.nrows) for c in range(self.wnm)]
-        for i in range(0, len(todo), self.batch_tiles):
-            batch = todo[i:i + self.batch_tiles]
+        if self.share_halo:                              # calls never span two tile rows
+            batches = [[(lr, c) for c in range(c0, min(c0 + self.batch_tiles, self.wnm))]
+                       for lr in range(self.nrows) for c0 in range(0, self.wnm, self.batch_tiles)]
+        else:
+            batches = [todo[i:i + self.batch_tiles] for i in range(0, len(todo), self.batch_tiles)]
+        for batch in batches:
             self.run_batch(batch, self.epoch)
             if self.state == "fp16":
                 # rows before the last one touched are complete; row q's old values are still read by row q+1
@@ -327,6 +377,41 @@ def device_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density: flo
             if zpad:
                 z = torch.zeros((cells, cells, zpad), device=dev)
                 core = torch.cat((z, core, z), dim=-1)
+            cache[(row, col)] = core
+        return cache[(row, col)]
+    return provider
+
+
+def consistent_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density: float = 0.02):
+    """Synthetic gene tiles that AGREE where neighbouring tiles overlap, like tiles cut with overlap from one gene map
+    (utils/MBADataset_tst.py:65-91): the map is a pure function of the absolute 16 x 16-cell block (seeded per block), a
+    tile's [20, 20, G] grid is assembled from its own block and the 2-cell rims of its eight neighbours.  Kept on the
+    device; the precondition of TileSweep(share_halo=True)."""
+    blocks, cache = {}, {}
+    zpad = Z_PAD[cfg.rna_slc] * tiles.GENES
+    blk = cfg.patch_size // cfg.gn_sz
+    ic, hc = tiles.TILE // blk, PAD // blk
+
+    def block(R, C):
+        if (R, C) not in blocks:
+            g = torch.Generator(device=dev)
+            g.manual_seed(2_000_003 * (R + 7) + (C + 7))
+            u = torch.rand((ic, ic, total_slc * tiles.GENES), generator=g, device=dev)
+            blocks[(R, C)] = torch.where(u < density, torch.floor(u * (3.0 / density)) + 1.0, torch.zeros_like(u))
+            for k in [k for k in blocks if abs(k[0] - R) > 2]:      # the sweep moves along the rows: keep a five-row band
+                del blocks[k]
+        return blocks[(R, C)]
+
+    def provider(row, col):
+        if (row, col) not in cache:
+            rs = [(row - 1, slice(ic - hc, ic)), (row, slice(0, ic)), (row + 1, slice(0, hc))]
+            cs = [(col - 1, slice(ic - hc, ic)), (col, slice(0, ic)), (col + 1, slice(0, hc))]
+            core = torch.cat([torch.cat([block(R, C)[sr, sc] for C, sc in cs], dim=1) for R, sr in rs], dim=0)
+            if zpad:
+                z = torch.zeros((ic + 2 * hc, ic + 2 * hc, zpad), device=dev)
+                core = torch.cat((z, core, z), dim=-1)
+            for k in [k for k in cache if k[0] != row]:             # one tile row of dense grids (41.6 MB each) at a time
+                del cache[k]
             cache[(row, col)] = core
         return cache[(row, col)]
     return provider

@@ -108,3 +108,22 @@ def test_tile_sweep_other_rna_slc(rna_slc, state_slc, gene_slc):
     assert got.shape == (state_slc * 2, 256, 256)
     d = (got.cpu() - ref).abs()
     assert d.max() <= 2e-3 and d.mean() <= 2e-5, util.report("sweep", got, ref)
+
+
+@pytest.mark.parametrize("dtype,state", [("f32", "fp32x2"), ("bf16", "fp16"), ("f16", "fp16")])
+def test_share_halo_window_is_bit_identical_to_per_tile_calls(dtype, state):
+    """TileSweep(share_halo=True): the tiles of a call as ONE window (the patch columns two neighbouring tiles share --
+    right halo of one, left interior edge of the next, utils/MBADataset_tst.py:91-123 -- go through the encoder once)
+    == one model call per tile as test_brn.py:174-226 does it, bit for bit, on gene tiles that agree where they overlap."""
+    from teramind_amd.brain import consistent_gene_provider
+    cfg = PathConfig(compute_dtype=dtype)
+    model = BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    genes = consistent_gene_provider(cfg, DEV, total_slc=SLC, density=0.05)
+    # neighbouring tiles see the same cells where their gene grids overlap
+    a, b = genes(3, 5), genes(3, 6)
+    assert torch.equal(a[:, 16:20], b[:, 0:4]) and float(a.sum()) > 0
+    kw = dict(hst=512, wst=1024, hnm=2, wnm=3, total_epochs=T, total_slc=SLC, device=DEV, init="device", state=state)
+    per_tile = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=1, **kw).test()
+    window = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, share_halo=True, **kw).test()
+    ragged = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=2, share_halo=True, **kw).test()
+    assert torch.equal(per_tile, window) and torch.equal(per_tile, ragged)

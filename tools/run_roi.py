@@ -41,7 +41,7 @@ def worker(args):
     import torch
     import teramind_amd  # noqa: F401
     from teramind_amd import launch, stitch
-    from teramind_amd.brain import GeneTileDir, device_gene_provider
+    from teramind_amd.brain import GeneTileDir, consistent_gene_provider, device_gene_provider
     from teramind_amd.config import PathConfig
     from teramind_amd.diffusion import SpacedDiffusionBeatGans
     from teramind_amd.unet import BeatGANsUNetModel
@@ -60,7 +60,7 @@ def worker(args):
     if args.gene_dir:
         genes = GeneTileDir(args.gene_dir, cfg, dev, total_slc=50, keep_resident=True)
     else:
-        genes = device_gene_provider(cfg, dev)
+        genes = consistent_gene_provider(cfg, dev) if args.share_halo else device_gene_provider(cfg, dev)
 
     class Deadline(Exception):
         pass
@@ -76,7 +76,8 @@ def worker(args):
     try:
         res = launch.run_sweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, hnm=args.hnm, wnm=args.wnm, total_epochs=T,
                                steps=T, warmup=0, device=dev, batch_tiles=args.batch_tiles, init=args.init, state=args.state,
-                               on_step=on_step, holder=holder)
+                               on_step=on_step, holder=holder, share_halo=bool(args.share_halo),
+                               prefetch_genes=not args.share_halo)
     except Deadline:
         # single-rank runs only (a rank that stops alone would leave its neighbours in the strip exchange)
         sw = holder["sweep"]
@@ -111,7 +112,7 @@ def worker(args):
                           "step_s": [round(v, 2) for v in per_step], "process_age_s": round(time.monotonic() - _T_START, 1),
                           "tile_files_written": d is not None, "dtype": args.dtype, "state": args.state, "tiles": tiles, "T": T,
                           "n_gpus": world, "genes": "on-disk COO .npz via GeneTileDir + tm_gene_tile_dense" if args.gene_dir else "synthetic, device resident",
-                          "init": args.init, "batch_tiles": args.batch_tiles,
+                          "init": args.init, "batch_tiles": args.batch_tiles, "share_halo": bool(args.share_halo),
                           "sweep_s": round(sweep_s, 2), "sweep_min": round(sweep_s / 60, 2), "s_per_tile_step": round(sweep_s * world / (tiles * T), 4),
                           "interior_patch_steps_per_s": round(400 * tiles * T / sweep_s, 1),
                           "first_step_s": round(per_step[0], 2), "last_step_s": round(per_step[-1], 2),
@@ -136,6 +137,9 @@ def main():
     ap.add_argument("--init", choices=["device", "reference"], default="device",
                     help="reference = the LCG-seeded CPU mt19937 noise of MBADataset_tst (slow: ~0.1 s per tile)")
     ap.add_argument("--batch_tiles", type=int, default=1)
+    ap.add_argument("--share_halo", type=int, default=0,
+                    help="1: the tiles of a model call form ONE window, patch columns shared by neighbouring tiles go through the "
+                         "encoder once (TileSweep(share_halo=True); needs gene tiles that agree where they overlap)")
     ap.add_argument("--gene_dir", default=None)
     ap.add_argument("--make_genes", type=int, default=0, help="write synthetic COO gene tiles with this many entries each into --gene_dir first")
     ap.add_argument("--out_dir", default=None)
