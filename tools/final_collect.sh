@@ -8,7 +8,7 @@ COMMIT=$(git rev-parse --short HEAD)
 SHA_BOX=$(cat $F/src_sha.txt)
 SHA_HERE=$(python3 tools/pmc_stamp.py)
 if [ "$SHA_BOX" != "$SHA_HERE" ]; then echo "kernel sources changed since the measurement ($SHA_BOX vs $SHA_HERE): re-measure"; exit 1; fi
-for n in f32 bf16 f16 tile_f32 tile_bf16 tile_f16 sweep_bf16_b7; do cp $F/bench_$n.json profiles/${R}_bench_$n.json; done
+for n in f32 bf16 f16 tile_f32 tile_bf16 tile_f16 sweep_bf16_b16 sweep_bf16_b16_noshare; do cp $F/bench_$n.json profiles/${R}_bench_$n.json; done
 {
   for W in "f32:(fp32, configs[1])" "bf16:--dtype bf16 (configs[1] shape)" "tile_f32:--tile (one test_brn tile per step, fp32)" "tile_bf16:--tile --dtype bf16"; do
     TAGW=${W%%:*}; D=${W#*:}

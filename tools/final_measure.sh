@@ -20,7 +20,8 @@ run bench_f16 200 python3 bench.py --dtype f16 --no-cpu-baseline --no-sweep
 run bench_tile_f32 200 python3 bench.py --tile --no-cpu-baseline --no-sweep --steps 5
 run bench_tile_bf16 200 python3 bench.py --tile --dtype bf16 --no-cpu-baseline --no-sweep --steps 5
 run bench_tile_f16 200 python3 bench.py --tile --dtype f16 --no-cpu-baseline --no-sweep --steps 5
-run bench_sweep_bf16_b7 300 python3 bench.py --sweep --sweep-hnm 2 --sweep-wnm 14 --sweep-batch-tiles 7 --steps 2 --warmup 1 --no-cpu-baseline
+run bench_sweep_bf16_b16 300 python3 bench.py --sweep --sweep-hnm 2 --sweep-wnm 16 --sweep-batch-tiles 16 --steps 2 --warmup 1 --no-cpu-baseline
+run bench_sweep_bf16_b16_noshare 300 python3 bench.py --sweep --sweep-hnm 2 --sweep-wnm 16 --sweep-batch-tiles 16 --sweep-share-halo 0 --steps 2 --warmup 1 --no-cpu-baseline
 echo "bench done"
 # kernel traces (the program itself after `--`: no env / shell hop under the profiler)
 for W in "f32:" "bf16:--dtype bf16" "tile_f32:--tile" "tile_bf16:--tile --dtype bf16"; do
