@@ -162,7 +162,7 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     res = launch.run_sweep(cfg, smp, model, genes, hnm=args.sweep_hnm, wnm=args.sweep_wnm, total_epochs=T, steps=steps,
                            warmup=warmup, device=dev, batch_tiles=args.sweep_batch_tiles, init="device", state="fp16",
                            on_step=on_step, after_warmup=lambda: model.profile(True), share_halo=share,
-                           prefetch_genes=not share)
+                           batch_rows=args.sweep_batch_rows if share else 1, prefetch_genes=not share)
     prof = model.profile_collect()
     model.profile(False)
     st = res["sweep"].local_state()
@@ -183,7 +183,8 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
                         f"16 interior patches, P=4) per diffusion step, DDIM-15 schedule, {args.sweep_dtype} UNet arithmetic, one "
                         f"float16 state canvas per rank, tile rows split over {world} rank(s)"),
            "tiles": tiles, "steps": steps, "warmup": warmup, "s_per_step": round(res["dt"] / steps, 4),
-           "tiles_per_model_call": args.sweep_batch_tiles,
+           "tiles_per_model_call": args.sweep_batch_tiles * (args.sweep_batch_rows if share else 1),
+           "window_tiles": [args.sweep_batch_rows if share else 1, args.sweep_batch_tiles],
            # one window per call: the patch columns neighbouring tiles share go through the encoder once (bit-identical for
            # gene tiles that agree where they overlap)
            "share_halo": share,
@@ -339,6 +340,7 @@ def main():
     ap.add_argument("--sweep-steps", type=int, default=2, help="timed diffusion steps of the appended sweep (1 warm-up step)")
     ap.add_argument("--sweep-dtype", choices=["bf16", "f16", "f32"], default="bf16")
     ap.add_argument("--sweep-batch-tiles", type=int, default=8, help="tiles of a tile row per model call")
+    ap.add_argument("--sweep-batch-rows", type=int, default=2, help="tile rows per model call (shared-halo windows only)")
     ap.add_argument("--sweep-share-halo", type=int, default=1,
                     help="1: the tiles of a call form one window (shared encoder patch columns computed once); 0: stacked tiles")
     ap.add_argument("--rehearse", action="store_true",

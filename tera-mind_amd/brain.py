@@ -36,7 +36,7 @@ class TileSweep:
                  hst: int = 256, wst: int = 256, hnm: int = 32, wnm: int = 32, total_epochs: int = 15,
                  total_slc: int = 50, device="cpu", rank: int = 0, world: int = 1, batch_tiles: int = 1,
                  group=None, init: str = "reference", noise_provider: Optional[Callable] = None,
-                 state: str = "fp32x2", share_halo: bool = False):
+                 state: str = "fp32x2", share_halo: bool = False, batch_rows: int = 1):
         """hst/wst/hnm/wnm/total_epochs mirror the test_brn CLI (test_brn.py:302-334).
         gene_provider(row, col) -> dense [20, 20, (total_slc + 2*zpad) * 500] gene tile (already
         block-summed and z-padded like MBADataset_tst._getgene/_pad_gn) for ABSOLUTE tile
@@ -58,8 +58,9 @@ class TileSweep:
                isolation (SURVEY 8e "global equivalence"), so the result is the same bit for bit PROVIDED the gene
                tiles agree where they overlap (they are cut with overlap from one gene map,
                utils/MBADataset_tst.py:65-91; `consistent_gene_provider` has that property, a per-tile seeded
-               provider does not).  The window's genes: every tile's own 16 interior cell columns, the outer halo
-               columns from the first / last tile."""
+               provider does not).  The window's genes: every tile's own 16 x 16 interior cells, the outer halo
+               cells from the window's edge tiles.  batch_rows (share_halo only): tile rows per window -- the halo
+               ROWS between them are shared the same way ((4 r + 1) x (4 k + 1) encoder patches for r x k tiles)."""
         if state not in ("fp32x2", "fp16"):
             raise ValueError(f"state {state!r}")
         self.state = state
@@ -76,6 +77,7 @@ class TileSweep:
         self.dev, self.rank, self.world, self.group = torch.device(device), rank, world, group
         self.batch_tiles, self.init, self.noise_provider = batch_tiles, init, noise_provider
         self.share_halo = bool(share_halo)
+        self.batch_rows = max(1, int(batch_rows)) if self.share_halo else 1
         self.r0, self.r1 = tiles.row_block_partition(hnm, world)[rank]
         self.nrows = self.r1 - self.r0
         H = self.nrows * tiles.TILE + 2 * PAD
@@ -126,24 +128,25 @@ class TileSweep:
                     t = self._noise_tile(self.row0 + row, self.col0 + c)
                     band[:, :, c * tiles.TILE:(c + 1) * tiles.TILE].copy_(t.permute(2, 0, 1))
             self._noise_rows[lr] = band
-            for k in [k for k in self._noise_rows if k < lr - 2]:
+            for k in [k for k in self._noise_rows if k < lr - 2 - self.batch_rows]:
                 del self._noise_rows[k]
         return self._noise_rows[lr]
 
-    def _strip(self, lr: int) -> torch.Tensor:
-        """[C, 256+64, W] float32: local tile row lr with its 32-px halo, as the step reads it."""
-        if lr in self._strips:
-            return self._strips[lr]
-        y = lr * tiles.TILE
+    def _strip(self, lr: int, nr: int = 1) -> torch.Tensor:
+        """[C, 256 nr + 64, W] float32: local tile rows lr .. lr + nr - 1 with their 32-px halo, as the step reads them."""
+        if (lr, nr) in self._strips:
+            return self._strips[(lr, nr)]
+        y, hh = lr * tiles.TILE, nr * tiles.TILE
         if self.epoch > 0:
-            st = self.cur[:, y:y + tiles.TILE + 2 * PAD, :].float()
+            st = self.cur[:, y:y + hh + 2 * PAD, :].float()
         else:
-            st = torch.full((self.chn, tiles.TILE + 2 * PAD, self.cur.shape[2]), -1.0, dtype=torch.float32, device=self.dev)
+            st = torch.full((self.chn, hh + 2 * PAD, self.cur.shape[2]), -1.0, dtype=torch.float32, device=self.dev)
             st[:, :PAD, PAD:-PAD] = self._noise_row(lr - 1)[:, -PAD:, :]
-            st[:, PAD:-PAD, PAD:-PAD] = self._noise_row(lr)
-            st[:, -PAD:, PAD:-PAD] = self._noise_row(lr + 1)[:, :PAD, :]
-        self._strips = {k: v for k, v in self._strips.items() if k >= lr - 1}
-        self._strips[lr] = st
+            for i in range(nr):
+                st[:, PAD + i * tiles.TILE:PAD + (i + 1) * tiles.TILE, PAD:-PAD] = self._noise_row(lr + i)
+            st[:, -PAD:, PAD:-PAD] = self._noise_row(lr + nr)[:, :PAD, :]
+        self._strips = {k: v for k, v in self._strips.items() if k[0] >= lr - 1}
+        self._strips[(lr, nr)] = st
         return st
 
     def _commit_rows(self, upto: int):
@@ -205,20 +208,25 @@ class TileSweep:
             return self._strip(lr)[:, :, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)
         return self.cur[:, y:y + tiles.TILE + 2 * PAD, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)     # 'h w c'
 
-    def _run_row_window(self, lr: int, c0: int, k: int, epoch: int):
-        """share_halo: tiles (lr, c0 .. c0 + k - 1) as one window -> [C, 256, 256 k] float32 result."""
+    def _run_row_window(self, lr: int, c0: int, k: int, epoch: int, nr: int = 1):
+        """share_halo: tiles (lr .. lr + nr - 1) x (c0 .. c0 + k - 1) as one window -> [C, 256 nr, 256 k] float32 result."""
         conf = self.conf
         x0, wpx = c0 * tiles.TILE, k * tiles.TILE + 2 * PAD
         if self.state == "fp16":
-            win = self._strip(lr)[:, :, x0:x0 + wpx]
+            win = self._strip(lr, nr)[:, :, x0:x0 + wpx]
         else:
             y = lr * tiles.TILE
-            win = self.cur[:, y:y + tiles.TILE + 2 * PAD, x0:x0 + wpx]
+            win = self.cur[:, y:y + nr * tiles.TILE + 2 * PAD, x0:x0 + wpx]
         blk = conf.patch_size // conf.gn_sz                                   # pixels per gene cell
         hc, ic = PAD // blk, tiles.TILE // blk                               # halo / interior cells per tile side
-        gts = [self.gene(self.row0 + self.r0 + lr, self.col0 + c0 + j).to(self.dev) for j in range(k)]
-        cols = [gts[0][:, :hc]] + [g[:, hc:hc + ic] for g in gts] + [gts[-1][:, hc + ic:]]
-        rna_hwc = torch.cat(cols, dim=1)[None]
+        bands = []
+        for i in range(nr):                                                   # one band of cell rows per tile row
+            gts = [self.gene(self.row0 + self.r0 + lr + i, self.col0 + c0 + j).to(self.dev) for j in range(k)]
+            band = torch.cat([gts[0][:, :hc]] + [g[:, hc:hc + ic] for g in gts] + [gts[-1][:, hc + ic:]], dim=1)
+            r0 = 0 if i == 0 else hc                                          # outer halo rows from the window's edge tiles
+            r1 = hc + ic + (hc if i == nr - 1 else 0)
+            bands.append(band[r0:r1])
+        rna_hwc = torch.cat(bands, dim=0)[None]
         x, rna, shape = tiles.run_batch_inputs(win.permute(1, 2, 0)[None], rna_hwc, conf.patch_size, conf.gn_sz,
                                                self.total_slc, conf.rna_slc)
         out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
@@ -230,18 +238,22 @@ class TileSweep:
         conf = self.conf
         if self.share_halo and len(tile_list) > 1:
             lr, c0 = tile_list[0]
-            if [(lr, c0 + j) for j in range(len(tile_list))] != list(tile_list):
-                raise ValueError("share_halo: the tiles of a call must be consecutive tiles of one row")
-            out = self._run_row_window(lr, c0, len(tile_list), epoch)
-            x0, x1 = c0 * tiles.TILE, (c0 + len(tile_list)) * tiles.TILE
-            if self.state == "fp16":
-                if lr not in self._pending:
-                    self._pending[lr] = torch.empty((self.chn, tiles.TILE, self.wnm * tiles.TILE), dtype=torch.float16,
-                                                    device=self.dev)
-                self._pending[lr][:, :, x0:x1].copy_(out.half())              # test_brn.py:222
-            else:
-                y = PAD + lr * tiles.TILE
-                self.nxt[:, y:y + tiles.TILE, PAD + x0:PAD + x1].copy_(out.half().float())
+            nr = tile_list[-1][0] - lr + 1
+            k = len(tile_list) // nr
+            if [(lr + i, c0 + j) for i in range(nr) for j in range(k)] != list(tile_list):
+                raise ValueError("share_halo: the tiles of a call must form a rectangle of consecutive rows and columns")
+            out = self._run_row_window(lr, c0, k, epoch, nr)
+            x0, x1 = c0 * tiles.TILE, (c0 + k) * tiles.TILE
+            for i in range(nr):
+                o = out[:, i * tiles.TILE:(i + 1) * tiles.TILE]
+                if self.state == "fp16":
+                    if lr + i not in self._pending:
+                        self._pending[lr + i] = torch.empty((self.chn, tiles.TILE, self.wnm * tiles.TILE), dtype=torch.float16,
+                                                            device=self.dev)
+                    self._pending[lr + i][:, :, x0:x1].copy_(o.half())        # test_brn.py:222
+                else:
+                    y = PAD + (lr + i) * tiles.TILE
+                    self.nxt[:, y:y + tiles.TILE, PAD + x0:PAD + x1].copy_(o.half().float())
             return
         tile_hwc = torch.stack([self._window(lr, c) for lr, c in tile_list])
         rna_hwc = torch.stack([self.gene(self.row0 + self.r0 + lr, self.col0 + c).to(self.dev) for lr, c in tile_list])
@@ -263,17 +275,18 @@ class TileSweep:
 
     def step(self):
         todo = [(lr, c) for lr in range(self.nrows) for c in range(self.wnm)]
-        if self.share_halo:                              # calls never span two tile rows
-            batches = [[(lr, c) for c in range(c0, min(c0 + self.batch_tiles, self.wnm))]
-                       for lr in range(self.nrows) for c0 in range(0, self.wnm, self.batch_tiles)]
+        if self.share_halo:                              # rectangles of batch_rows x batch_tiles tiles (ragged at the edges)
+            batches = [[(lr, c) for lr in range(l0, min(l0 + self.batch_rows, self.nrows))
+                        for c in range(c0, min(c0 + self.batch_tiles, self.wnm))]
+                       for l0 in range(0, self.nrows, self.batch_rows) for c0 in range(0, self.wnm, self.batch_tiles)]
         else:
             batches = [todo[i:i + self.batch_tiles] for i in range(0, len(todo), self.batch_tiles)]
         for batch in batches:
             self.run_batch(batch, self.epoch)
             if self.state == "fp16":
-                # rows before the last one touched are complete; row q's old values are still read by row q+1
-                done = batch[-1][0] - (0 if batch[-1][1] == self.wnm - 1 else 1)
-                self._commit_rows(done - 1)
+                # a row group is complete once its call reaches the last column; the old values of its LAST row are still
+                # read by the row group below (top halo), the old values of the row above the group by its remaining calls
+                self._commit_rows(batch[-1][0] - 1 if batch[-1][1] == self.wnm - 1 else batch[0][0] - 2)
         if self.state == "fp16":
             self._commit_rows(self.nrows)
             self._strips, self._noise_rows = {}, {}

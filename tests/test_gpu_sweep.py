@@ -127,3 +127,9 @@ def test_share_halo_window_is_bit_identical_to_per_tile_calls(dtype, state):
     window = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, share_halo=True, **kw).test()
     ragged = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=2, share_halo=True, **kw).test()
     assert torch.equal(per_tile, window) and torch.equal(per_tile, ragged)
+    # windows of several tile rows: the halo rows between them are shared too
+    kw3 = dict(kw, hnm=3)
+    per_tile3 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=1, **kw3).test()
+    rows2 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=2, batch_rows=2, share_halo=True, **kw3).test()
+    rows3 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, batch_rows=3, share_halo=True, **kw3).test()
+    assert torch.equal(per_tile3, rows2) and torch.equal(per_tile3, rows3)
