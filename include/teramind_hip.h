@@ -205,8 +205,10 @@ int tm_op_from_cb8(const void* x_cb8, void* y_ncdhw, int N, int C, int Z, int H,
 /* Conv3d on the MFMA implicit-GEMM kernels (replaces nn.Conv3d as used in ResBlock,
  * model/MBAblocks.py:146-148,182-186,220-224, the RNA pyramid convs model/unet_ours.py:290-295
  * and down_z model/MBAblocks.py:472-474).  ksize 1: 1x1x1.  ksize 3 with zmode
- *   0: 3x3x3 pad (1,1,1), Z == 2      1: 1x3x3 pad (0,1,1)      2: 3x3x3 pad (0,1,1) (Zout = Z-2).
- * up2: nearest x2 on (H, W) applied to the output.  w [Cout][Cin][kz][3][3] HOST fp32,
+ *   0: 3x3x3 pad (1,1,1), Z == 2      1: 1x3x3 pad (0,1,1)      2: 3x3x3 pad (0,1,1) (Zout = Z-2)
+ *   3: 3x3x3 pad (1,1,1) of the nearest-x2 UPSAMPLED x (Upsample then Conv3d as in ResBlock(up=True), model/MBAblocks.py:254-258,
+ *      blocks.py:362-371), Z == 2, computed on x itself with per-phase 2x2 in-plane weights: y is [N, Cout, Z, 2S, 2S].
+ * up2: nearest x2 on (H, W) applied to the output (not with zmode 3).  w [Cout][Cin][kz][3][3] HOST fp32,
  * bias [Cout] HOST fp32; x, y CB8 DEVICE. */
 int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
                     int N, int Cin, int Cout, int Z, int S, int ksize, int zmode, int up2,

@@ -72,6 +72,7 @@ struct ConvArgs {
   // gate tensor at HALF the in-plane resolution ([N][Cob][Z][S/2][S/2][8], read at (z, y >> 1, x >> 1)): the adaLN gates are
   // Linear(SiLU(cond)) of a nearest-x2 upsampled RNA level, i.e. constant over 2 x 2 voxel blocks.  gate_ls = log2(S), 0 = off
   int gate_ls = 0;
+  int res_ls = 0;                   // the same for the fp32 residual `res` (3x3x3 conv epilogue): = log2(S), 0 = off
 };
 
 // in-plane element offset of voxel (z, y, x) -> (z, y >> 1, x >> 1) of the half-resolution plane; ls = log2(S)
@@ -108,7 +109,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
       for (int mt = 0; mt < WM; ++mt) {
         ok[g][mt] = cob < a.Cob && ooff[mt] >= 0;
         const long pl = ok[g][mt] ? (long)cob * a.y_plane + ooff[mt] + 4 * h : 0;
-        if (a.res) rv[g][mt] = *(const f32x4*)(a.res + (ok[g][mt] ? (long)on[mt] * a.res_nstride : 0) + pl);
+        if (a.res) {
+          const long rpl = !a.res_ls ? pl : (ok[g][mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.res_ls) + 4 * h : 0);
+          rv[g][mt] = *(const f32x4*)(a.res + (ok[g][mt] ? (long)on[mt] * a.res_nstride : 0) + rpl);
+        }
         if (a.gate) {
           const long gpl = !a.gate_ls ? pl : (ok[g][mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.gate_ls) + 4 * h : 0);
           gv[g][mt] = *(const f32x4*)(a.gate + (ok[g][mt] ? (long)on[mt] * a.gate_nstride : 0) + gpl);

@@ -35,10 +35,13 @@ size_t conv_pack_floats(int Cout, int Cbi, int taps);
 // host-side packing; seg_c[i] = real channels of concat segment i (each padded to x8).
 void conv_pack_host(const float* w /*[Cout][Cin][taps]*/, int Cout, const int* seg_c, int nseg,
                     int taps, float* out);
+size_t conv_pack_ups_floats(int Cout, int Cbi);          // phase weights of the upsampled-input conv (ZM_UPS), taps = 12
+void conv_pack_ups_host(const float* w /*[Cout][Cin][27]*/, int Cout, const int* seg_c, int nseg, float* out);
 void vec_pack_host(const float* v, const int* seg_c, int nseg, float* out);  // per-cin vector -> virtual order
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_UP2 = 2 };
-enum { ZM_PAD1 = 0, ZM_INPLANE = 1, ZM_VALID = 2 };   // z structure of a k x 3 x 3 conv (see conv3d_mfma)
+enum { ZM_PAD1 = 0, ZM_INPLANE = 1, ZM_VALID = 2,    // z structure of a k x 3 x 3 conv (see conv3d_mfma)
+       ZM_UPS = 3 };                                   // 3x3x3 pad 1 of nearest-x2 upsampled x, computed on x (conv_pack_ups_host weights)
 struct ConvLaunch {
   TV x;                  // activated input, Cb == w.Cbi
   ConvW w;
@@ -48,6 +51,8 @@ struct ConvLaunch {
   int flags = 0;
   int tile_variant = 0;  // 0 auto, 1 = 128-voxel blocks, 2 = 256-voxel blocks
   int gate_half = 0;     // taps == 1 only: `gate` lives at S/2 and is read at (z, y >> 1, x >> 1) (S a power of two)
+  int res_half = 0;      // k x 3 x 3 only: `res` lives at S/2 and is read at (z, y >> 1, x >> 1): the residual of a ResBlock(up=True)
+                         // is the nearest-x2 upsampled block input (model/MBAblocks.py:254-258,297)
   int zmode = ZM_PAD1;   // ignored for taps == 1
 };
 hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s);

@@ -24,7 +24,14 @@ namespace tmk {
 //   NZI = 3  3x3x3 over three staged planes zo + zi + zoff: zoff = 0 is valid-in-z (Zin = Zout + 2: down_z,
 //            model/MBAblocks.py:472-474), zoff = -1 with planes outside [0, Zin) zero is pad (1,1,1) for any Z
 //            (the ResBlock convs of the z_size 4 / 8 configs, rna_slc 8 / 16)
-template <int NZI, int WM, int TW>
+//   UPS (with NZI = 2)  the same 3x3x3 conv applied to a nearest-x2 UPSAMPLED input (ResBlock(up=True): Upsample then
+//            in_layers, model/MBAblocks.py:254-258, blocks.py:362-371), computed on the LOW-resolution tensor: output voxel
+//            (2y + py, 2x + px) sees only the 2 x 2 low-resolution voxels (y + py - 1 .. y + py, x + px - 1 .. x + px), so
+//            each of the four phases (py, px) is a conv with 2 x 2 in-plane taps whose weights are the sums of the 3 x 3
+//            taps that land on the same source voxel (packed per phase by conv_pack_ups_host): 8 instead of 18 taps per
+//            output plane and a quarter of the input bytes; the zero padding of the upsampled tensor maps onto the zero
+//            halo of the low-resolution tile.  Same sums, different association (weights are added before the products).
+template <int NZI, int WM, int TW, bool UPS = false>
 struct C3Geo {
   static constexpr int MV = 4 * WM * 32;                         // voxels per workgroup
   static constexpr int TR = (MV / TW < TW) ? (MV / TW) : TW;     // tile rows (<= plane size S == TW or 2*TW)
@@ -33,20 +40,22 @@ struct C3Geo {
   static constexpr int XV = NPB * NZI * HR * HC;                 // halo voxels
   static constexpr int XPIECES = XV * 2;                         // 16-byte pieces
   static constexpr int PX = (XPIECES + 255) / 256;
-  static constexpr int NTAP = 9 * NZI;                           // taps staged per channel block
+  static constexpr int TZ = UPS ? 4 : 9;                         // in-plane taps
+  static constexpr int NTAP = TZ * NZI;                          // taps staged per channel block
   static constexpr int WFLOATS = NTAP * 512;
   static constexpr int WPIECES = WFLOATS / 4;
   static constexpr int PW = (WPIECES + 255) / 256;
-  static constexpr int TAPS_TOTAL = (NZI == 1) ? 9 : 27;         // taps per channel block in the packed weights
-  // channel blocks per stage: the 9-tap in-plane form has half the MFMAs per block of the 18-tap z-skip form, so it
-  // stages two blocks per barrier pair to keep the same MFMA phase length
-  static constexpr int KB = (NZI == 1) ? 2 : 1;
+  static constexpr int TAPS_TOTAL = (NZI == 1) ? 9 : 3 * TZ;     // taps per channel block in the packed weights
+  // channel blocks per stage: the 9-tap in-plane form (and the 8-tap upsampled form) has half the MFMAs per block of the
+  // 18-tap z-skip form, so it stages two blocks per barrier pair to keep the same MFMA phase length
+  static constexpr int KB = (NZI == 1 || UPS) ? 2 : 1;
   static constexpr int LDS_BYTES = KB * (WFLOATS + XV * 8) * 4;
 };
 
-template <int NZI, int WM, int TW>
+template <int NZI, int WM, int TW, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
-  using G = C3Geo<NZI, WM, TW>;
+  using G = C3Geo<NZI, WM, TW, UPS>;
+  static_assert(!UPS || NZI == 2, "the upsampled-input form exists for the z-skip conv only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KB = G::KB;
   float* lw = lds;                                               // [KB][NTAP][512]
@@ -62,6 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;
   int mt_ = bid / a.ntile;
+  int py = 0, px = 0;                                            // UPS: output phase of this workgroup (the four phases of a
+  if (UPS) { py = (mt_ >> 1) & 1; px = mt_ & 1; mt_ >>= 2; }     // tile are neighbours in the grid: they share the input halo)
   const int pg = mt_ / (a.Z * tiles);                            // a.Z = OUTPUT planes
   mt_ -= pg * a.Z * tiles;
   const int zo = mt_ / tiles;
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
     xoff[k] = off;
   }
   // weights: the staged taps of this (n-tile, cblk) are contiguous; NZI == 2 starts at kz = 1 - zo
-  const int tap0 = (NZI == 2) ? (1 - zo) * 9 : 0;
-  const float* wsrc = a.w + ((long)nt * a.Cbi * G::TAPS_TOTAL + tap0) * 512 + tid * 4;
+  const int tap0 = (NZI == 2) ? (1 - zo) * G::TZ : 0;
+  const float* wsrc = a.w + (((long)(UPS ? (py * 2 + px) * a.ntile : 0) + nt) * a.Cbi * G::TAPS_TOTAL + tap0) * 512 + tid * 4;
   const long w_cb_stride = G::TAPS_TOTAL * 512;
 
   // ---- per-lane fragment addresses ----
@@ -108,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
     on[mt] = n;
     const int y = tr * G::TR + r, x = tc * TW + c;
     if (n < a.N) {
-      if (a.flags & EPI_UP2) ooff[mt] = ((zo * 2 * S + 2 * y) * 2 * S + 2 * x) * 8;
+      if (UPS) ooff[mt] = ((zo * 2 * S + 2 * y + py) * 2 * S + 2 * x + px) * 8;
+      else if (a.flags & EPI_UP2) ooff[mt] = ((zo * 2 * S + 2 * y) * 2 * S + 2 * x) * 8;
       else ooff[mt] = ((zo * S + y) * S + x) * 8;
     } else ooff[mt] = -1;
   }
@@ -161,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma(ConvArgs a) {
 #pragma unroll
       for (int zi = 0; zi < NZI; ++zi) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
+        for (int ky = 0; ky < (UPS ? 2 : 3); ++ky) {
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int tap = zi * 9 + ky * 3 + kx;
-            const int xd = kb * G::XV * 8 + ((zi * G::HR + ky) * G::HC + kx) * 8;
+          for (int kx = 0; kx < (UPS ? 2 : 3); ++kx) {
+            const int tap = UPS ? zi * 4 + ky * 2 + kx : zi * 9 + ky * 3 + kx;
+            const int xd = kb * G::XV * 8 + ((zi * G::HR + ky + py) * G::HC + kx + px) * 8;
             f32x4 wf[2], xf[WM];
             wf[0] = *(const f32x4*)(lw + kb * G::WFLOATS + tap * 512 + wb);
             wf[1] = *(const f32x4*)(lw + kb * G::WFLOATS + tap * 512 + 256 + wb);
@@ -327,6 +339,32 @@ void conv_pack_host(const float* w, int Cout, const int* seg_c, int nseg, int ta
   (void)ntile;
 }
 
+// Phase weights of the upsampled-input conv (C3Geo, UPS): for output phase (py, px) the 3 x 3 in-plane taps collapse onto a
+// 2 x 2 window of the low-resolution input -- rows: py = 0: {ky 0} | {ky 1, 2}; py = 1: {ky 0, 1} | {ky 2}; columns alike.
+// out: [phase = 2 py + px][conv_pack_host layout with 12 taps (kz, ky', kx')]
+size_t conv_pack_ups_floats(int Cout, int Cbi) { return 4 * conv_pack_floats(Cout, Cbi, 12); }
+void conv_pack_ups_host(const float* w /*[Cout][Cin][27]*/, int Cout, const int* seg_c, int nseg, float* out) {
+  int Cin = 0, Cbi = 0;
+  for (int s = 0; s < nseg; ++s) { Cin += seg_c[s]; Cbi += (seg_c[s] + 7) / 8; }
+  static const int G0[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};       // [phase bit][window pos] -> tap range [lo, hi]
+  const size_t per = conv_pack_floats(Cout, Cbi, 12);
+  float* weff = (float*)malloc((size_t)Cout * Cin * 12 * sizeof(float));
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      for (size_t i = 0; i < (size_t)Cout * Cin; ++i)
+        for (int kz = 0; kz < 3; ++kz)
+          for (int wy = 0; wy < 2; ++wy)
+            for (int wx = 0; wx < 2; ++wx) {
+              float acc = 0.f;
+              for (int ky = G0[py][wy][0]; ky <= G0[py][wy][1]; ++ky)
+                for (int kx = G0[px][wx][0]; kx <= G0[px][wx][1]; ++kx) acc += w[i * 27 + kz * 9 + ky * 3 + kx];
+              weff[i * 12 + kz * 4 + wy * 2 + wx] = acc;
+            }
+      conv_pack_host(weff, Cout, seg_c, nseg, 12, out + (size_t)(py * 2 + px) * per);
+    }
+  free(weff);
+}
+
 void vec_pack_host(const float* v, const int* seg_c, int nseg, float* out) {
   int ci0 = 0, cb0 = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -388,11 +426,43 @@ hipError_t launch_conv_mfma(const ConvLaunch& L, hipStream_t s) {
   } else if (L.zmode == ZM_VALID) {    // 3x3x3 valid in z
     if (L.w.taps != 27 || L.y.Z != L.x.Z - 2) return hipErrorInvalidValue;
     nzi = 3;
+  } else if (L.zmode == ZM_UPS) {      // 3x3x3 pad 1 of the nearest-x2 upsampled x, on the low-resolution x (phase weights)
+    if (L.w.taps != 12 || L.x.Z != 2 || L.y.Z != 2 || (L.flags & EPI_UP2) || L.res || L.gate) return hipErrorInvalidValue;
+    nzi = 2;
   } else return hipErrorInvalidValue;
   a.Z = L.y.Z;
   if (S != 4 && S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
-  if ((L.flags & EPI_UP2) ? (L.y.H != 2 * S) : (L.y.H != S)) return hipErrorInvalidValue;
+  if (((L.flags & EPI_UP2) || L.zmode == ZM_UPS) ? (L.y.H != 2 * S) : (L.y.H != S)) return hipErrorInvalidValue;
+  if (L.res_half) {
+    int ls = 0;
+    while ((1 << ls) < L.y.H) ++ls;
+    if (!L.res || (1 << ls) != L.y.H || L.y.H != L.y.W || ls < 1 || (L.flags & EPI_UP2)) return hipErrorInvalidValue;
+    a.res_ls = ls;
+  }
   const long ovox = (long)a.N * a.Z * a.S * a.S;
+  if (L.zmode == ZM_UPS) {
+#define TM_LAUNCHU(WM, TW)                                                                       \
+  do {                                                                                          \
+    using G = C3Geo<2, WM, TW, true>;                                                           \
+    static DevOnce attr_once;                                                                   \
+    if (attr_once.need()) {                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_mfma<2, WM, TW, true>,             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_once.mark();                                                                         \
+    }                                                                                           \
+    const long tiles = (long)(S / TW) * (S / G::TR);                                            \
+    const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
+    const long grid = pgs * a.Z * tiles * 4 * a.ntile;                                          \
+    hipLaunchKernelGGL((conv3d_mfma<2, WM, TW, true>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a); \
+  } while (0)
+    const int variant = L.tile_variant ? L.tile_variant : ((ovox / 256) * 4 * a.ntile >= 512 ? 2 : 1);
+    if (S < 8) { if (S != 4) return hipErrorInvalidValue; TM_LAUNCHU(1, 4); }
+    else if (variant == 2) { if (S >= 32) TM_LAUNCHU(2, 32); else if (S == 16) TM_LAUNCHU(2, 16); else TM_LAUNCHU(2, 8); }
+    else { if (S >= 32) TM_LAUNCHU(1, 32); else if (S == 16) TM_LAUNCHU(1, 16); else TM_LAUNCHU(1, 8); }
+#undef TM_LAUNCHU
+    return hipGetLastError();
+  }
   int variant = L.tile_variant ? L.tile_variant : ((ovox / 256) * a.ntile >= 512 ? 2 : 1);
 #define TM_LAUNCH3(NZI, WM, TW)                                                                  \
   do {                                                                                          \

@@ -47,7 +47,8 @@ struct ResW {
   std::vector<int> seg;       // real channels of each concat source
   int cin = 0, cbi = 0, cout = 0;
   bool has_skip = false;
-  ConvW c1, c2, skip;
+  bool up = false;            // ResBlock(up=True): in_layers' conv also packed as phase weights of the upsampled-input form
+  ConvW c1, c2, skip, c1u;
   const float* n1 = nullptr;  // [cbi*8] virtual order
   const float* n2 = nullptr;  // [cout]
   const uint16_t *c1h = nullptr, *c2h = nullptr;   // bf16 packed 3x3x3 weights (TM_DTYPE_BF16)
@@ -260,6 +261,7 @@ static int build_graph(tm_model* m) {
         const std::string pu = p + "." + std::to_string(nxt);
         spec_res(s, pu, ch, ch, E);
         e.ops.push_back({0, add_res(m, pu, {ch}, ch), RS_UP2});
+        m->res.back().up = true;
       }
       m->dec.push_back(e);
       ++k;
@@ -567,6 +569,17 @@ extern "C" int tm_model_finalize(tm_model* m) {
         pack_conv_h(m, pk, fx, fxh, r.c2, &r.c2h, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout});
       } else {
         pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27, m->z == 1);
+        if (r.up && m->z == 2) {                             // phase weights (conv3d_mfma UPS form) + their own copy of the bias
+          r.c1u = r.c1;
+          r.c1u.taps = 12;
+          const size_t off = pk.reserve(conv_pack_ups_floats(r.cout, r.cbi));
+          conv_pack_ups_host(P(m, r.pfx + ".in_layers.2.weight").data(), r.cout, r.seg.data(), (int)r.seg.size(), pk.buf.data() + off);
+          fx.push_back({&r.c1u.w, off});
+          const size_t boff = pk.reserve((size_t)r.c1u.ntile * 64);
+          const std::vector<float>& b = P(m, r.pfx + ".in_layers.2.bias");
+          for (int i = 0; i < r.cout; ++i) pk.buf[boff + i] = b[i];
+          fx.push_back({&r.c1u.bias, boff});
+        }
         pack_conv(m, pk, fx, r.c2, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout}, 27, m->z == 1);
       }
       if (r.has_skip) {
@@ -741,10 +754,11 @@ static void dump_tv(Ctx& cx, const std::string& name, const TV& t_in) {
 }
 
 static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, const TV* gate, int flags,
-                     int cin_real = 0, int zmode = ZM_PAD1, bool gate_half = false) {
+                     int cin_real = 0, int zmode = ZM_PAD1, bool gate_half = false, bool res_half = false) {
   if (cx.dry) return;
   ConvLaunch L;
   L.x = x; L.w = w; L.y = y; L.res = res; L.gate = gate; L.flags = flags; L.zmode = zmode; L.gate_half = gate_half ? 1 : 0;
+  L.res_half = res_half ? 1 : 0;
   tm_model* m = cx.m;
   const bool prof = m->prof_on && (w.taps == 27 || (m->z == 1 && w.taps == 9)) && zmode == ZM_PAD1;
   if (prof) {
@@ -898,6 +912,39 @@ static TV res_block(Ctx& cx, const ResW& w, const std::vector<Src>& src, int N, 
   const int Z = m->z;
   TV out = out_opt ? *out_opt : cx.tensor(N, w.cout, Z, S_out);
   const size_t mark = cx.top;
+  static const bool no_ups = getenv("TM_CONV_UPS") && atoi(getenv("TM_CONV_UPS")) == 0;           // A/B timing only
+  if (mode == RS_UP2 && w.c1u.w && !no_ups && src.size() == 1 && !src[0].collage && !w.has_skip && !(S_out & (S_out - 1))) {
+    // ResBlock(up=True) (MBAblocks.py:254-261,297): h = Upsample(x) feeds in_layers, x = Upsample(x) is the residual.  Nothing
+    // is upsampled here: norm and SiLU act per voxel, so they run on the low-resolution x (a quarter of the bytes); the first
+    // conv is the upsampled-input form of conv3d_mfma (per-phase 2 x 2 in-plane weights, 8 instead of 18 taps); the second
+    // conv's epilogue reads the residual at (z, y >> 1, x >> 1) of x itself.
+    const int S_in = S_out / 2;
+    TV A = cx.tensor(N, w.cbi * 8, Z, S_in);
+    if (!cx.dry) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = src[0].t.p; P.src[0].nstride = src[0].t.nstride; P.src[0].Cb = src[0].t.Cb;
+      P.N = N; P.Z = Z; P.S = S_in; P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
+      P.out = A.p; P.out_nstride = A.nstride;
+      cx.check(launch_prep(P, cx.s));
+    }
+    TV A2 = cx.tensor(N, w.cout, Z, S_out), H1 = cx.tensor(N, w.cout, Z, S_out);
+    run_conv(cx, A, w.c1u, H1, nullptr, nullptr, 0, w.cin, ZM_UPS);
+    if (!cx.dry) {
+      PrepLaunch P;
+      P.nsrc = 1;
+      P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
+      P.N = N; P.Z = Z; P.S = S_out;
+      P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
+      P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
+      P.mod_stride = m->emb_tot;
+      P.out = A2.p; P.out_nstride = A2.nstride;
+      cx.check(launch_prep(P, cx.s));
+    }
+    run_conv(cx, A2, w.c2, out, &src[0].t, nullptr, 0, 0, ZM_PAD1, false, true);
+    cx.top = mark;
+    return out;
+  }
   int cin_pad = w.cbi * 8;
   TV A = cx.tensor(N, cin_pad, Z, S_out), raw, H1, A2;
   // the residual / skip-conv input is the CONCATENATED (and resampled) x, MBAblocks.py:252-258,297:
@@ -1459,14 +1506,17 @@ extern "C" int tm_op_from_cb8(const void* x, void* y, int N, int C, int Z, int H
 extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
                                int Cout, int Z, int S, int ksize, int zmode, int up2, int tile_variant, void* stream) {
   if (ksize != 1 && ksize != 3) return fail(TM_ERR_ARG, "ksize must be 1 or 3");
-  if (zmode != ZM_PAD1 && zmode != ZM_INPLANE && zmode != ZM_VALID) return fail(TM_ERR_ARG, "bad zmode");
-  const int taps = ksize == 1 ? 1 : (zmode == ZM_INPLANE ? 9 : 27);
+  if (zmode != ZM_PAD1 && zmode != ZM_INPLANE && zmode != ZM_VALID && zmode != ZM_UPS) return fail(TM_ERR_ARG, "bad zmode");
+  const bool ups = ksize == 3 && zmode == ZM_UPS;       // w [Cout][Cin][27]: conv of the nearest-x2 upsampled x (y at 2S)
+  if (zmode == ZM_UPS && (ksize != 3 || up2)) return fail(TM_ERR_ARG, "ZM_UPS: ksize 3, no fused upsample of the output");
+  const int taps = ksize == 1 ? 1 : (zmode == ZM_INPLANE ? 9 : (ups ? 12 : 27));
   const int Zout = (ksize == 3 && zmode == ZM_VALID) ? Z - 2 : Z;
-  const int So = up2 ? 2 * S : S;
+  const int So = (up2 || ups) ? 2 * S : S;
   ConvW cw;
   cw.Cout = Cout; cw.Cbi = (Cin + 7) / 8; cw.taps = taps; cw.ntile = (Cout + 63) / 64;
-  std::vector<float> pk(conv_pack_floats(Cout, cw.Cbi, taps)), bp((size_t)cw.ntile * 64, 0.f);
-  conv_pack_host((const float*)w_host, Cout, &Cin, 1, taps, pk.data());
+  std::vector<float> pk(ups ? conv_pack_ups_floats(Cout, cw.Cbi) : conv_pack_floats(Cout, cw.Cbi, taps)), bp((size_t)cw.ntile * 64, 0.f);
+  if (ups) conv_pack_ups_host((const float*)w_host, Cout, &Cin, 1, pk.data());
+  else conv_pack_host((const float*)w_host, Cout, &Cin, 1, taps, pk.data());
   memcpy(bp.data(), bias_host, Cout * sizeof(float));
   float *dw = nullptr, *db = nullptr;
   HIP_TRY(hipMalloc((void**)&dw, pk.size() * sizeof(float)));

@@ -293,6 +293,20 @@ def test_prep_h16_forms_bit_identical(cins, flags, mod, dtype):
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,S", [(2, 16, 64, 8), (3, 24, 128, 4), (1, 72, 64, 16), (2, 8, 64, 32), (1, 128, 128, 32)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_conv3_upsampled_input_phase_form_exact_integers(N, Cin, Cout, S, variant):
+    """Upsample (nearest x2) -> Conv3d(3, pad 1) of ResBlock(up=True) (model/MBAblocks.py:254-258, blocks.py:362-371)
+    computed on the low-resolution tensor with per-phase 2 x 2 in-plane weights (sums of the 3 x 3 taps): integer operands
+    make both associations exact, so the result must equal F.conv3d on the upsampled tensor bit for bit."""
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 61)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 62)
+    b = util.rand_int((Cout,), -4, 4, 63)
+    ref = F.conv3d(x.repeat_interleave(2, 3).repeat_interleave(2, 4), w, b, padding=1)
+    got, _ = util.conv_mfma(x.to(DEV), w, b, 3, variant=variant, zmode=3)
+    assert torch.equal(got.cpu(), ref), util.report("conv3 upsampled-input", got, ref)
+
+
 def test_conv27_bf16_random_vs_bf16_rounded_reference():
     g = torch.Generator().manual_seed(17)
     N, Cin, Cout, S = 2, 741, 512, 8

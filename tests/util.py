@@ -49,7 +49,7 @@ def conv_mfma(x, w, b, ksize, variant=0, zmode=0, up2=False):
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
     Zo = Z - 2 if (ksize == 3 and zmode == 2) else Z
-    So = 2 * S if up2 else S
+    So = 2 * S if (up2 or zmode == 3) else S
     xc = to_cb8(x)
     yc = torch.zeros((N, (Cout + 7) // 8, Zo, So, So, 8), dtype=torch.float32, device=x.device)
     wh, bh = w.contiguous().float(), b.contiguous().float()
