@@ -219,10 +219,14 @@ int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void* bias_host
  * the 4-wave (128 x 256 / 64 x 512 tile) or 8-wave (128 x 512 / 64 x 1024) workgroup form.
  * res_h16 (nullable): 16-bit CB8 residual [N][ceil(Cout/8)][2][S][S][8] added in fp32 before the final rounding;
  * y_h16 (nullable): write the result as a 16-bit CB8 tensor of that shape INSTEAD of y_cb8 (the 16-bit activation
- * stream of the model: block outputs and residuals are 16-bit tensors, as under the reference's fp16 autocast). */
+ * stream of the model: block outputs and residuals are 16-bit tensors, as under the reference's fp16 autocast).
+ * ups != 0: the conv of the nearest-x2 UPSAMPLED x (ResBlock(up=True), model/MBAblocks.py:254-258), computed on x itself with
+ * per-phase 2x2 in-plane weights: outputs are [N, Cout, 2, 2S, 2S]; Cout a multiple of 128, no residual.
+ * res_half != 0: res_h16 is [N][ceil(Cout/8)][2][S/2][S/2][8] and read at (z, y >> 1, x >> 1) (the residual of that block:
+ * the upsampled block input, :297). */
 int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8,
                       int N, int Cin, int Cout, int S, int dtype, int waves, const void* res_h16, void* y_h16,
-                      void* stream);
+                      int ups, int res_half, void* stream);
 
 /* The same conv with the ResBlock mid-section fused into its epilogue (Cout in {64, 128}): out_layers[0]
  * RMSNorm(C) * norm_w -> x * (1 + scale) + shift -> SiLU (model/MBAblocks.py:196-203,356-367), written as the 16-bit CB8

@@ -34,6 +34,7 @@
 #define launch_conv1_bf16 launch_conv1_f16
 #define launch_window_attn_bf16 launch_window_attn_f16
 #define conv_bf16_pack_host conv_f16_pack_host
+#define conv_bf16_pack_ups_host conv_f16_pack_ups_host
 #define conv1_bf16_pack_host conv1_f16_pack_host
 #else
 #define TM_H16_T __bf16
@@ -187,7 +188,10 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
       for (int mt = 0; mt < 4; ++mt) {
         ok[mt] = cob < a.Cob && ooff[mt] >= 0;
         pl[mt] = ok[mt] ? (long)cob * a.y_plane + ooff[mt] : 0;
-        if (a.res_h) rb[mt] = *(const h16x8*)(a.res_h + (ok[mt] ? (long)on[mt] * a.res_h_nstride : 0) + pl[mt]);
+        if (a.res_h) {
+          const long rpl = !a.res_ls ? pl[mt] : (ok[mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.res_ls) : 0);
+          rb[mt] = *(const h16x8*)(a.res_h + (ok[mt] ? (long)on[mt] * a.res_h_nstride : 0) + rpl);
+        }
         if (GATE && a.gate_h) {
           const long gpl = !a.gate_ls ? pl[mt] : (ok[mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.gate_ls) : 0);
           gb[mt] = *(const h16x8*)(a.gate_h + (ok[mt] ? (long)on[mt] * a.gate_h_nstride : 0) + gpl);
@@ -257,7 +261,12 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
 //   TW = 32: column i -> (row, i): G1 and G2 each cover 16 distinct residues of one row (natural map);
 //   TW = 16: G1 -> row 0, G2 -> row 1 of the 2-row MFMA tile;
 //   TW =  8: pitch 12, G1 -> rows 0 and 2, G2 -> rows 1 and 3 of the 4-row MFMA tile.
-template <int TN, int TW, int NWV = 8>
+// UPS: the 3x3x3 conv of a nearest-x2 UPSAMPLED input (ResBlock(up=True), model/MBAblocks.py:254-258) computed on the
+// low-resolution tensor, as conv3d_mfma's UPS form (tm_kernels.hip): output phase (py, px) of low-resolution voxel (y, x)
+// is a conv with 2 x 2 in-plane taps over (y + py - 1 .. y + py, x + px - 1 .. x + px) and pre-summed weights.  Four taps
+// per plane would make a stage too short to cover its own LDS-DMA, so a stage is (channel-block pair, BOTH input planes):
+// 8 taps, two halo images.
+template <int TN, int TW, int NWV = 8, bool UPS = false>
 struct HGeo {
   static constexpr int NT = NWV * 64;                 // threads: 8 waves (128 x 512 / 64 x 1024 tile) or 4 (half the voxels:
                                                       // twice the workgroups for launches that would leave CUs idle)
@@ -270,11 +279,13 @@ struct HGeo {
   static constexpr int HCP = (TW == 8) ? 12 : HC;     // slot pitch of a halo row
   static constexpr int XS = NPB * HR * HCP;           // slots of ONE k-half of ONE input plane
   static constexpr int XSP = (XS + 63) / 64 * 64;     // k-half arrays start on a wave's 64-slot boundary (LDS-DMA)
-  static constexpr int XPIECES = XSP * 2;             // piece i -> LDS slot WPIECES + i
+  static constexpr int NPL = UPS ? 2 : 1;             // input planes per stage
+  static constexpr int NTAPS = UPS ? 8 : 9;           // taps per stage
+  static constexpr int XPIECES = XSP * 2 * NPL;       // piece i -> LDS slot WPIECES + i  ([plane][k-half][slot])
   static constexpr int PX = (XPIECES + NT - 1) / NT;
-  static constexpr int WPIECES = 9 * TN * 2;
+  static constexpr int WPIECES = NTAPS * TN * 2;
   static constexpr int PW = (WPIECES + NT - 1) / NT;
-  static constexpr int BUF16 = WPIECES + 2 * XSP;     // 16-byte units per LDS buffer
+  static constexpr int BUF16 = WPIECES + 2 * XSP * NPL;   // 16-byte units per LDS buffer
   static constexpr int LDS_BYTES = 2 * BUF16 * 16;
 };
 
@@ -308,9 +319,10 @@ __device__ unsigned int g_tm_stamp_next = 0;
 #define TM_STAMP(i) do { } while (0)
 #endif
 
-template <int TN, int TW, bool FUSE, int NWV = 8>
+template <int TN, int TW, bool FUSE, int NWV = 8, bool UPS = false>
 __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
-  using G = HGeo<TN, TW, NWV>;
+  using G = HGeo<TN, TW, NWV, UPS>;
+  constexpr int NTAPS = G::NTAPS;
   constexpr int NT = G::NT;
   const ConvArgs& a = ah.c;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
     if (k < g_tm_stamp_cap) {
       stamp_slot = g_tm_stamps + (size_t)k * 8;
       stamp_slot[4] = gridDim.x; stamp_slot[5] = blockIdx.x;
-      stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + (unsigned long long)(TN * 1000 + TW * 10 + (FUSE ? 1 : 0));
+      stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + (unsigned long long)(TN * 1000 + TW * 10 + (FUSE ? 1 : 0) + (UPS ? 2 : 0));
       stamp_slot[7] = __builtin_amdgcn_s_memrealtime();
     }
   }
@@ -339,6 +351,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;                        // n-tile of TN couts
   int mt_ = bid / a.ntile;
+  int py = 0, px = 0;                                  // UPS: output phase (the four phases of a tile are grid neighbours)
+  if (UPS) { py = (mt_ >> 1) & 1; px = mt_ & 1; mt_ >>= 2; }
   const int pg = mt_ / (a.Z * tiles);                  // a.Z output (= input) planes, pad 1 in z
   mt_ -= pg * a.Z * tiles;
   const int zo = mt_ / tiles;
@@ -357,8 +371,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
     const int i = tid + k * NT;
     long off = -1;
     if (i < G::XPIECES) {
-      const int half = i / G::XSP;
-      int v = i - half * G::XSP;
+      const int pl = i / (2 * G::XSP);                 // plane of the stage (UPS: both input planes; otherwise 0)
+      const int half = (i - pl * 2 * G::XSP) / G::XSP;
+      int v = i - (pl * 2 + half) * G::XSP;
       if (v < G::XS) {
         const int hc = v % G::HCP; v /= G::HCP;
         const int hr = v % G::HR;
@@ -366,13 +381,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
         const int n = pg * G::NPB + ps;
         const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
         if (hc < G::HC && n < a.N && y >= 0 && y < S && x >= 0 && x < S)
-          off = (long)n * ah.x_nstride_e + (long)half * ah.x_plane_e + ((long)y * S + x) * 8;
+          off = (long)n * ah.x_nstride_e + (long)half * ah.x_plane_e + (long)pl * S * S * 8 + ((long)y * S + x) * 8;
       }
     }
     xoff[k] = off;
   }
-  // packed weights: [n-tile][pair][kz 3][9 taps][TN][2][8]
-  const h16_t* wsrc = wg + (long)nt * ah.Cbp * 27 * TN * 16 + (long)tid * 8;
+  // packed weights: [n-tile][pair][kz 3][9 taps][TN][2][8]; UPS: [phase][n-tile][pair][kz 3][4 taps][TN][2][8]
+  const h16_t* wsrc = UPS ? wg + ((long)(py * 2 + px) * a.ntile + nt) * ah.Cbp * 12 * TN * 16 + (long)tid * 8
+                          : wg + (long)nt * ah.Cbp * 27 * TN * 16 + (long)tid * 8;
 
   // ---- fragment addresses (16-byte units inside a buffer) ----
   int xb[4], on[4], ooff[4];
@@ -384,9 +400,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
     const int n = pg * G::NPB + ps;
     on[mt] = n;
     const int y = tr * G::TR + r, x = tc * TW + c;
-    ooff[mt] = (n < a.N) ? ((zo * S + y) * S + x) * 8 : -1;
+    if (UPS) ooff[mt] = (n < a.N) ? ((zo * 2 * S + 2 * y + py) * 2 * S + 2 * x + px) * 8 : -1;
+    else ooff[mt] = (n < a.N) ? ((zo * S + y) * S + x) * 8 : -1;
   }
   const int wb = (wn * 64 + i32) * 2 + (h ^ ((i32 >> 3) & 1));
+  // fragment offset of tap t inside a buffer: weights t * TN * 2; activations relative to xb[]
+  auto tap_xd = [&](int t) __attribute__((always_inline)) {
+    return UPS ? (t >> 2) * 2 * G::XSP + (((t >> 1) & 1) + py) * G::HCP + (t & 1) + px : (t / 3) * G::HCP + (t % 3);
+  };
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -406,19 +427,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   // one stage = (channel-block pair, input plane zi): global -> LDS by LDS-DMA, no staging registers.  Output plane zo
   // reads the input planes [zo-1, zo+1] that exist (kz = zi + 1 - zo): 2 of 3 for the z_size-2 checkpoint model, 1 for
   // z_size 1, 2 or 3 for z_size 4 / 8 -- planes in the zero padding are never staged nor multiplied
-  const int zi0 = zo > 0 ? zo - 1 : 0;
-  const int npl = (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;
+  const int zi0 = UPS ? 0 : (zo > 0 ? zo - 1 : 0);
+  const int npl = UPS ? 1 : (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;      // stages per channel-block pair
   // LDS-DMA piece p (0 .. PW + PX - 1) of stage hs: the weight pieces first, then the halo-tile pieces
   auto issue_piece = [&](int hs, int p) __attribute__((always_inline)) {
     const int cbp = hs / npl, zi = zi0 + hs % npl;
     u32x4* base = lds16 + (hs & 1) * G::BUF16;
     if (p < G::PW) {
       const int k = p;
-      const h16_t* wp = wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
+      // UPS (Z == 2): the stage's planes 0, 1 meet kz = 1 - zo, 2 - zo: eight consecutive taps of the phase's 12
+      const h16_t* wp = UPS ? wsrc + ((long)cbp * 3 + (1 - zo)) * 4 * TN * 16 : wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
       if (G::WPIECES % NT == 0 || k * NT + wv * 64 < G::WPIECES) TM_GLDS16(wp + (long)k * NT * 8, base + k * NT + wv * 64);
     } else {
       const int k = p - G::PW;
-      const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (long)zi * S * S * 8;
+      const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (UPS ? 0 : (long)zi * S * S * 8);
       if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * NT + wv * 64);
     }
   };
@@ -447,14 +469,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
     wf[2][0] = __builtin_bit_cast(bf16x8, buf0[wb]);
     wf[2][1] = __builtin_bit_cast(bf16x8, buf0[64 + wb]);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) xf[2][mt] = __builtin_bit_cast(bf16x8, buf0[xb[mt]]);
+    for (int mt = 0; mt < 4; ++mt) xf[2][mt] = __builtin_bit_cast(bf16x8, buf0[xb[mt] + tap_xd(0)]);
   }
   for (int hs = 0; hs < NH; ++hs) {
     const bool more = hs + 1 < NH;
     const u32x4* buf = lds16 + (hs & 1) * G::BUF16;
     const u32x4* nbuf = lds16 + ((hs + 1) & 1) * G::BUF16;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NTAPS; ++tap) {
       const int cur = tap == 0 ? 2 : ((tap - 1) & 1);
       const int nxt = tap & 1;                             // set of tap + 1 (taps 1 .. 8)
       // This tap's fragments were requested one tap ago, behind eight MFMAs: they have long landed.  Saying so HERE, before
@@ -462,9 +484,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
       // lgkmcnt(6) in this loop), which would expose a full LDS round trip in front of every second MFMA group.
       __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) only (vmcnt / expcnt fields = no wait)
       __builtin_amdgcn_sched_barrier(0);
-      if (tap < 8) {
+      if (tap < NTAPS - 1) {
         const int t1 = tap + 1;
-        const int xd = (t1 / 3) * G::HCP + (t1 % 3);
+        const int xd = tap_xd(t1);
         if (!(TM_ABL & 2)) {
           wf[nxt][0] = __builtin_bit_cast(bf16x8, buf[t1 * TN * 2 + wb]);
           wf[nxt][1] = __builtin_bit_cast(bf16x8, buf[t1 * TN * 2 + 64 + wb]);
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
           wf[2][0] = __builtin_bit_cast(bf16x8, nbuf[wb]);
           wf[2][1] = __builtin_bit_cast(bf16x8, nbuf[64 + wb]);
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) xf[2][mt] = __builtin_bit_cast(bf16x8, nbuf[xb[mt]]);
+          for (int mt = 0; mt < 4; ++mt) xf[2][mt] = __builtin_bit_cast(bf16x8, nbuf[xb[mt] + tap_xd(0)]);
         }
       }
       // keep tap t+1's ds_reads above tap t's MFMAs (hipcc otherwise sinks them to just before their use and
@@ -1250,6 +1272,50 @@ void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, u
   }
 }
 
+// Phase weights of the upsampled-input conv (HGeo UPS; the fp32 twin is conv_pack_ups_host): per output phase (py, px) the
+// 3 x 3 in-plane taps collapse onto a 2 x 2 window of the low-resolution input -- rows: py = 0: {ky 0} | {ky 1, 2};
+// py = 1: {ky 0, 1} | {ky 2}; columns alike; the sums are formed in fp32 and rounded once.
+// out: [phase = 2 py + px][n-tile][pair][kz 3][4 taps (wy, wx)][TN][2][8]
+#ifndef TM_H16_F16
+size_t conv_bf16_pack_ups_elems(int Cout, int Cbi) {
+  const int TN = conv_bf16_tn(Cout);
+  return (size_t)4 * ((Cout + TN - 1) / TN) * ((Cbi + 1) / 2) * 12 * TN * 16;
+}
+#endif
+void conv_bf16_pack_ups_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out) {
+  int Cin = 0, Cbi = 0;
+  for (int s = 0; s < nseg; ++s) { Cin += seg_c[s]; Cbi += (seg_c[s] + 7) / 8; }
+  const int TN = conv_bf16_tn(Cout), Cbp = (Cbi + 1) / 2, ntile = (Cout + TN - 1) / TN;
+  static const int G0[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};       // [phase bit][window pos] -> tap range [lo, hi]
+  memset(out, 0, conv_bf16_pack_ups_elems(Cout, Cbi) * sizeof(uint16_t));
+  for (int ph = 0; ph < 4; ++ph) {
+    const int py = ph >> 1, px = ph & 1;
+    int ci0 = 0, cb0 = 0;
+    for (int s = 0; s < nseg; ++s) {
+      for (int c = 0; c < seg_c[s]; ++c) {
+        const int ci = ci0 + c, cb = cb0 + c / 8, c8 = c % 8;
+        const int pair = cb >> 1, half = cb & 1;
+        for (int co = 0; co < Cout; ++co) {
+          const int nt = co / TN, col = co % TN;
+          const int slot = half ^ ((col >> 3) & 1);
+          const float* src = w + ((size_t)co * Cin + ci) * 27;
+          uint16_t* dst = out + (((((size_t)ph * ntile + nt) * Cbp + pair) * 12) * TN + col) * 16 + slot * 8 + c8;
+          for (int kz = 0; kz < 3; ++kz)
+            for (int wy = 0; wy < 2; ++wy)
+              for (int wx = 0; wx < 2; ++wx) {
+                float acc = 0.f;
+                for (int ky = G0[py][wy][0]; ky <= G0[py][wy][1]; ++ky)
+                  for (int kx = G0[px][wx][0]; kx <= G0[px][wx][1]; ++kx) acc += src[kz * 9 + ky * 3 + kx];
+                dst[(size_t)(kz * 4 + wy * 2 + wx) * TN * 16] = f32_to_bf16_rne(acc);
+              }
+        }
+      }
+      ci0 += seg_c[s];
+      cb0 += (seg_c[s] + 7) / 8;
+    }
+  }
+}
+
 #ifndef TM_H16_F16
 size_t conv1_bf16_pack_elems(int Cout, int Cbi) {
   const int TN = conv_bf16_tn(Cout);
@@ -1399,10 +1465,44 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   ah.mod_stride = L.mod_stride; ah.per_image = L.per_image; ah.inv_c = 1.0f / (float)L.Cout;
   ah.a2 = L.a2.p; ah.a2_nstride = L.a2.nstride;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
-  if (L.x.Cb & 1 || L.x.Z < 1 || L.y.Z != L.x.Z || L.x.H != L.x.W || L.y.H != L.x.H || L.y.N != L.x.N)
+  if (L.x.Cb & 1 || L.x.Z < 1 || L.y.Z != L.x.Z || L.x.H != L.x.W || L.y.H != (L.ups ? 2 : 1) * L.x.H || L.y.N != L.x.N)
     return hipErrorInvalidValue;
   const int S = a.S, TN = conv_bf16_tn(L.Cout);
   a.ntile = (L.Cout + TN - 1) / TN;
+  if (L.res_half) {
+    int ls = 0;
+    while ((1 << ls) < L.y.H) ++ls;
+    if (!L.res_h || (1 << ls) != L.y.H || L.y.H != L.y.W || ls < 1) return hipErrorInvalidValue;
+    a.res_ls = ls;
+  }
+  if (L.ups) {
+    // upsampled-input form: TN = 128 only (the up blocks of the model family have Cout >= 128), Z == 2, no residual
+    if (TN != 128 || L.x.Z != 2 || L.res || L.res_h || (S != 8 && S != 16 && S != 32 && S != 64)) return hipErrorInvalidValue;
+    if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
+    if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8)) return hipErrorInvalidValue;
+#define TM_LAUNCHU(TW_, NWV_)                                                                    \
+  do {                                                                                          \
+    using G = HGeo<128, TW_, NWV_, true>;                                                       \
+    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget of the upsampled-input form");        \
+    static DevOnce attr_done;                                                                   \
+    if (attr_done.need()) {                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)conv27_bf16<128, TW_, false, NWV_, true>, \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_bf16<128, TW_, true, NWV_, true>, \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_done.mark();                                                                         \
+    }                                                                                           \
+    const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
+    const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
+    const long grid = pgs * a.Z * tiles * 4 * a.ntile;                                          \
+    if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<128, TW_, true, NWV_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+    else hipLaunchKernelGGL((conv27_bf16<128, TW_, false, NWV_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+  } while (0)
+    if (S >= 32) TM_LAUNCHU(32, 8); else if (S == 16) TM_LAUNCHU(16, 8); else TM_LAUNCHU(8, 4);
+#undef TM_LAUNCHU
+    return hipGetLastError();
+  }
   if (L.y.Cb > a.ntile * (TN / 8)) return hipErrorInvalidValue;
   if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res || L.res_h)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;

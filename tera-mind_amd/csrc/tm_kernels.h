@@ -91,6 +91,9 @@ struct ConvLaunchH {
   TVH a2;
   int force_waves = 0;              // 0 = auto, 4 | 8 = workgroup form (tests / A-B; TM_CONV27_WAVES, TM_CONV1_WAVES)
   int gate_half = 0;                // conv1 only: gate_h lives at S/2 and is read at (z, y >> 1, x >> 1) (S a power of two)
+  int res_half = 0;                 // conv27 only: res_h lives at S/2 and is read at (z, y >> 1, x >> 1)
+  int ups = 0;                      // conv27 only: x is the LOW-resolution tensor (y.H == 2 x.H), w = conv_bf16_pack_ups_host weights:
+                                    // the conv of the nearest-x2 upsampled x (Cout a multiple of 128, Z == 2, no residual)
   // conv1 only: input = channel concat of nsrc (1..3) 16-bit CB8 tensors read in place, each optionally through the collage
   // remap of a (p1 x p2) source patch grid; `x` then only carries N, Z, H, W and the even-padded block count (x.p unused)
   int nsrc = 0;
@@ -106,6 +109,9 @@ void conv1_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, 
 hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s);
 size_t conv_bf16_pack_elems(int Cout, int Cbi);
 void conv_bf16_pack_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
+size_t conv_bf16_pack_ups_elems(int Cout, int Cbi);
+void conv_bf16_pack_ups_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
+void conv_f16_pack_ups_host(const float* w, int Cout, const int* seg_c, int nseg, uint16_t* out);
 hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s);
 hipError_t launch_window_attn_bf16(const TVH& q, const TVH& k, const TVH& v, const float* qnorm_w, const float* knorm_w,
                                    TVH o, hipStream_t s);

@@ -52,6 +52,7 @@ struct ResW {
   const float* n1 = nullptr;  // [cbi*8] virtual order
   const float* n2 = nullptr;  // [cout]
   const uint16_t *c1h = nullptr, *c2h = nullptr;   // bf16 packed 3x3x3 weights (TM_DTYPE_BF16)
+  const uint16_t* c1uh = nullptr;                  // up blocks: in_layers' conv as phase weights of the upsampled-input form
   const uint16_t* skiph = nullptr;
   int emb_off = 0;
 };
@@ -567,6 +568,12 @@ extern "C" int tm_model_finalize(tm_model* m) {
       if (bf16) {
         pack_conv_h(m, pk, fx, fxh, r.c1, &r.c1h, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg);
         pack_conv_h(m, pk, fx, fxh, r.c2, &r.c2h, r.pfx + ".out_layers.3.weight", r.pfx + ".out_layers.3.bias", r.cout, {r.cout});
+        if (r.up && m->z == 2 && r.cout % 128 == 0) {          // phase weights of the upsampled-input form (bias: c1's)
+          const size_t off = pk.reserve((conv_bf16_pack_ups_elems(r.cout, r.cbi) + 1) / 2);
+          (c.dtype == TM_DTYPE_F16 ? conv_f16_pack_ups_host : conv_bf16_pack_ups_host)(
+              P(m, r.pfx + ".in_layers.2.weight").data(), r.cout, r.seg.data(), (int)r.seg.size(), (uint16_t*)(pk.buf.data() + off));
+          fxh.push_back({&r.c1uh, off});
+        }
       } else {
         pack_conv(m, pk, fx, r.c1, r.pfx + ".in_layers.2.weight", r.pfx + ".in_layers.2.bias", r.cout, r.seg, 27, m->z == 1);
         if (r.up && m->z == 2) {                             // phase weights (conv3d_mfma UPS form) + their own copy of the bias
@@ -782,10 +789,10 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
 // y: geometry of the output; y16: `y.p` is a 16-bit stream tensor (written as such); res16: 16-bit stream residual
 static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw, TV y, const TV* res16, int cin_real,
                        const TVH* fuse_a2 = nullptr, const ResW* rw = nullptr, int per_image = 1, bool y16 = false,
-                       bool count = true) {
+                       bool count = true, bool ups = false, bool res_half = false) {
   if (cx.dry) return;
   ConvLaunchH L;
-  L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y;
+  L.x = x; L.w = w; L.bias = cw.bias; L.Cout = cw.Cout; L.y = y; L.ups = ups ? 1 : 0; L.res_half = res_half ? 1 : 0;
   TVH resh;
   if (res16) { resh = as_h(*res16); L.res_h = &resh; }
   if (y16) { L.y_h = (uint16_t*)y.p; L.yh_nstride = y.nstride; }
@@ -841,6 +848,48 @@ static TV res_block_h16(Ctx& cx, const ResW& w, const std::vector<Src>& src, int
   TV out = cx.tensor_s(N, w.cout, Z, S_out);
   const size_t mark = cx.top;
   const int cbe = (w.cbi + 1) / 2 * 2;
+  static const bool no_ups = getenv("TM_CONV_UPS") && atoi(getenv("TM_CONV_UPS")) == 0;           // A/B timing only
+  if (mode == RS_UP2 && w.c1uh && !no_ups && src.size() == 1 && !src[0].collage && !w.has_skip && !(S_out & (S_out - 1)) &&
+      S_out >= 16) {
+    // ResBlock(up=True) (MBAblocks.py:254-261,297) without upsampling anything: norm + SiLU on the low-resolution x, the first
+    // conv in its upsampled-input form (per-phase 2 x 2 in-plane weights: 8 instead of 18 taps), the second conv's epilogue
+    // reads the residual Upsample(x) at (z, y >> 1, x >> 1) of x itself (see the fp32 twin in res_block)
+    const int S_in = S_out / 2;
+    TVH Al = cx.tensor_h(N, cbe, Z, S_in);
+    if (!cx.dry) {
+      PrepLaunch P;
+      P.nsrc = 1; P.src_h = 1; P.h_f16 = h_f16;
+      P.src[0].p = src[0].t.p; P.src[0].nstride = src[0].t.nstride; P.src[0].Cb = src[0].t.Cb;
+      P.N = N; P.Z = Z; P.S = S_in; P.norm_w = w.n1; P.inv_c = 1.0f / (float)w.cin; P.act = 1; P.per_image = per_image;
+      P.out_h = Al.p; P.out_h_nstride = Al.nstride; P.pad_blocks = Al.Cb - w.cbi;
+      cx.check(launch_prep(P, cx.s));
+    }
+    const bool fuse_up = w.cout == 128;
+    TVH A2u = cx.tensor_h(N, (w.cout / 8 + 1) / 2 * 2, Z, S_out);
+    TV geom_u; geom_u.N = N; geom_u.C = w.cout; geom_u.Cb = w.cout / 8; geom_u.Z = Z; geom_u.H = S_out; geom_u.W = S_out;
+    geom_u.nstride = (long)geom_u.Cb * geom_u.plane();
+    if (fuse_up) {
+      run_conv_h(cx, Al, w.c1uh, w.c1, geom_u, nullptr, w.cin, &A2u, &w, per_image, false, false, true);
+    } else {
+      TV H1 = cx.tensor_s(N, w.cout, Z, S_out);
+      run_conv_h(cx, Al, w.c1uh, w.c1, H1, nullptr, w.cin, nullptr, nullptr, 1, true, false, true);
+      if (!cx.dry) {
+        PrepLaunch P;
+        P.nsrc = 1;
+        P.src[0].p = H1.p; P.src[0].nstride = H1.nstride; P.src[0].Cb = H1.Cb;
+        P.src_h = 1;
+        P.N = N; P.Z = Z; P.S = S_out;
+        P.norm_w = w.n2; P.inv_c = 1.0f / (float)w.cout; P.act = 1; P.per_image = per_image;
+        P.mod = MOD_IMAGE; P.mod_scale = cx.ss + w.emb_off; P.mod_shift = cx.ss + w.emb_off + w.cout;
+        P.mod_stride = m->emb_tot;
+        P.out_h = A2u.p; P.out_h_nstride = A2u.nstride; P.pad_blocks = A2u.Cb - w.cout / 8; P.h_f16 = h_f16;
+        cx.check(launch_prep(P, cx.s));
+      }
+    }
+    run_conv_h(cx, A2u, w.c2h, w.c2, out, &src[0].t, w.cout, nullptr, nullptr, 1, true, true, false, true);
+    cx.top = mark;
+    return out;
+  }
   TVH Ah = cx.tensor_h(N, cbe, Z, S_out), rawh;
   // The concatenated / re-tiled x (MBAblocks.py:252-258,297) is only materialised where it is the RESIDUAL of a block
   // without skip conv (the up / down blocks: resampled x); the skip conv reads the sources in place (conv1's concat input)
@@ -1541,7 +1590,8 @@ extern "C" int tm_op_conv_mfma(const void* x_cb8, const void* w_host, const void
 // shared body of the 16-bit 3x3x3 conv test entry points: fp32 CB8 input -> 16-bit CB8 (prep kernel), then the conv
 static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin, int Cout,
                          int S, int dtype, int waves, const void* norm_w_host, const void* scale_host, const void* shift_host,
-                         int per_image, void* a2_out, void* stream, const void* res_h16 = nullptr, void* y_h16 = nullptr) {
+                         int per_image, void* a2_out, void* stream, const void* res_h16 = nullptr, void* y_h16 = nullptr,
+                         int ups = 0, int res_half = 0) {
   if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
   if (waves != 0 && waves != 4 && waves != 8) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4 or 8");
   const bool f16 = dtype == TM_DTYPE_F16, fused = norm_w_host != nullptr;
@@ -1549,8 +1599,11 @@ static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias
     return fail(TM_ERR_ARG, "fused epilogue needs Cout in {64, 128}, scale / shift / a2 and per_image >= 1");
   hipStream_t st = (hipStream_t)stream;
   const int Cbi = (Cin + 7) / 8, Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64;
-  std::vector<uint16_t> pk(conv_bf16_pack_elems(Cout, Cbi));
-  (f16 ? conv_f16_pack_host : conv_bf16_pack_host)((const float*)w_host, Cout, &Cin, 1, pk.data());
+  if (ups && (Cout % 128 || res_h16)) return fail(TM_ERR_ARG, "upsampled-input form: Cout a multiple of 128, no residual");
+  const int So = ups ? 2 * S : S;                       // output plane size
+  std::vector<uint16_t> pk(ups ? conv_bf16_pack_ups_elems(Cout, Cbi) : conv_bf16_pack_elems(Cout, Cbi));
+  if (ups) (f16 ? conv_f16_pack_ups_host : conv_bf16_pack_ups_host)((const float*)w_host, Cout, &Cin, 1, pk.data());
+  else (f16 ? conv_f16_pack_host : conv_bf16_pack_host)((const float*)w_host, Cout, &Cin, 1, pk.data());
   const int nimg = (N + per_image - 1) / per_image;
   // one device buffer of floats: bias | norm_w | scale [nimg][Cout] | shift [nimg][Cout]
   std::vector<float> fp((size_t)nt64 * 64 + (fused ? (size_t)Cout * (1 + 2 * nimg) : 0), 0.f);
@@ -1578,15 +1631,19 @@ static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias
   ConvLaunchH L;
   L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = 2; L.x.H = S; L.x.W = S; L.x.nstride = P.out_h_nstride;
   L.w = dw; L.bias = df; L.Cout = Cout; L.force_waves = waves;
-  L.y = view_cb8(y_cb8, N, Cout, 2, S, S);
+  L.y = view_cb8(y_cb8, N, Cout, 2, So, So);
+  L.ups = ups; L.res_half = res_half;
   TVH resh = as_h(L.y);
-  if (res_h16) { resh.p = (uint16_t*)const_cast<void*>(res_h16); L.res_h = &resh; }
+  if (res_h16) {
+    resh.p = (uint16_t*)const_cast<void*>(res_h16); L.res_h = &resh;
+    if (res_half) { resh.H = So / 2; resh.W = So / 2; resh.nstride = L.y.nstride / 4; }
+  }
   if (y_h16) { L.y_h = (uint16_t*)y_h16; L.yh_nstride = L.y.nstride; }
   if (fused) {
     L.fuse_norm = 1; L.norm_w = df + nt64 * 64; L.mod_scale = L.norm_w + Cout; L.mod_shift = L.mod_scale + (size_t)nimg * Cout;
     L.mod_stride = Cout; L.per_image = per_image;
-    L.a2.p = (uint16_t*)a2_out; L.a2.N = N; L.a2.Cb = Cout / 8; L.a2.C = Cout; L.a2.Z = 2; L.a2.H = S; L.a2.W = S;
-    L.a2.nstride = (long)(Cout / 8) * vox * 8;
+    L.a2.p = (uint16_t*)a2_out; L.a2.N = N; L.a2.Cb = Cout / 8; L.a2.C = Cout; L.a2.Z = 2; L.a2.H = So; L.a2.W = So;
+    L.a2.nstride = (long)(Cout / 8) * 2 * So * So * 8;
   }
   hipError_t e = (f16 ? launch_conv27_f16 : launch_conv27_bf16)(L, st);
   hipError_t e2 = hipStreamSynchronize(st);
@@ -1597,10 +1654,11 @@ static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias
   return TM_OK;
 }
 extern "C" int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
-                                 int Cout, int S, int dtype, int waves, const void* res_h16, void* y_h16, void* stream) {
+                                 int Cout, int S, int dtype, int waves, const void* res_h16, void* y_h16, int ups, int res_half,
+                                 void* stream) {
   if (!x_cb8 || !w_host || !bias_host || (!y_cb8 && !y_h16)) return fail(TM_ERR_ARG, "null argument");
   return op_conv27_h16(x_cb8, w_host, bias_host, y_cb8 ? y_cb8 : y_h16, N, Cin, Cout, S, dtype, waves, nullptr, nullptr, nullptr, 1,
-                       nullptr, stream, res_h16, y_h16);
+                       nullptr, stream, res_h16, y_h16, ups, res_half);
 }
 extern "C" int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const void* bias_host, const void* norm_w_host,
                                   const void* scale_host, const void* shift_host, void* a2_out, int N, int Cin, int Cout,

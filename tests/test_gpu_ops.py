@@ -307,6 +307,35 @@ def test_conv3_upsampled_input_phase_form_exact_integers(N, Cin, Cout, S, varian
     assert torch.equal(got.cpu(), ref), util.report("conv3 upsampled-input", got, ref)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,S", [(2, 16, 128, 8), (3, 40, 128, 16), (1, 128, 128, 32), (2, 64, 256, 8), (1, 32, 256, 16)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv27_16bit_upsampled_input_phase_form_exact_integers(N, Cin, Cout, S, dtype):
+    """The 16-bit twin of the upsampled-input conv: Upsample (nearest x2) -> Conv3d(3, pad 1) of ResBlock(up=True)
+    (model/MBAblocks.py:254-258) on the low-resolution tensor with per-phase 2 x 2 weights.  Small integers: the summed
+    weights (|w| <= 8) and every product are exact in bf16 / f16, so the result equals F.conv3d on the upsampled tensor."""
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 71)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 72)
+    b = util.rand_int((Cout,), -4, 4, 73)
+    ref = F.conv3d(x.repeat_interleave(2, 3).repeat_interleave(2, 4), w, b, padding=1)
+    got, _ = util.conv27_bf16(x.to(DEV), w, b, dtype, ups=True)
+    assert torch.equal(got.cpu(), ref), util.report("conv27 16-bit upsampled-input " + dtype, got, ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv27_16bit_residual_at_half_resolution(dtype):
+    """res + conv with the residual stored at S/2 and read at (z, y >> 1, x >> 1): the residual of ResBlock(up=True) is the
+    upsampled block input (model/MBAblocks.py:297)."""
+    td = util.H16[dtype][1]
+    N, Cin, Cout, S = 2, 24, 128, 16
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 75)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 76)
+    b = util.rand_int((Cout,), -4, 4, 77)
+    res = util.rand_int((N, Cout, 2, S // 2, S // 2), -50, 50, 78)
+    ref = (res.repeat_interleave(2, 3).repeat_interleave(2, 4) + F.conv3d(x, w, b, padding=1)).to(td).float()
+    got, _ = util.conv27_bf16(x.to(DEV), w, b, dtype, res=res.to(DEV), out16=True, res_half=True)
+    assert torch.equal(got.cpu(), ref), util.report("conv27 half-resolution residual " + dtype, got, ref)
+
+
 def test_conv27_bf16_random_vs_bf16_rounded_reference():
     g = torch.Generator().manual_seed(17)
     N, Cin, Cout, S = 2, 741, 512, 8

@@ -67,21 +67,22 @@ def to_cb8_h16(x, dtype):
     return to_cb8(x).to(H16[dtype][1])
 
 
-def conv27_bf16(x, w, b, dtype="bf16", waves=0, res=None, out16=False):
+def conv27_bf16(x, w, b, dtype="bf16", waves=0, res=None, out16=False, ups=False, res_half=False):
     """x NCDHW cuda (Z == 2); rounds x (device) and w (host) to the 16-bit `dtype`, fp32 accumulate.
     waves: 0 = the launcher's choice, 4 / 8 = force that workgroup form.  res: NCDHW residual handed over as a 16-bit CB8
     tensor; out16: take the result as a 16-bit CB8 tensor (the model's activation-stream form).  Returns fp32 NCDHW."""
     N, Cin, Z, S, _ = x.shape
     Cout = w.shape[0]
     xc = to_cb8(x)
-    shp = (N, (Cout + 7) // 8, Z, S, S, 8)
+    So = 2 * S if ups else S       # ups: the conv of the nearest-x2 upsampled x, computed on x; res_half: res lives at So / 2
+    shp = (N, (Cout + 7) // 8, Z, So, So, 8)
     yc = torch.zeros(shp, dtype=torch.float32, device=x.device) if not out16 else None
     yh = torch.zeros(shp, dtype=H16[dtype][1], device=x.device) if out16 else None
     rh = to_cb8_h16(res, dtype) if res is not None else None
     wh, bh = w.contiguous().float(), b.contiguous().float()
     _lib.check(_lib.lib().tm_op_conv27_bf16(_lib.ptr(xc), C.c_void_p(wh.data_ptr()), C.c_void_p(bh.data_ptr()), _lib.ptr(yc),
                                             N, Cin, Cout, S, H16[dtype][0], waves, _lib.ptr(rh), _lib.ptr(yh),
-                                            _lib.current_stream_ptr()), "tm_op_conv27_bf16")
+                                            int(ups), int(res_half), _lib.current_stream_ptr()), "tm_op_conv27_bf16")
     yc = yh.float() if out16 else yc
     return from_cb8(yc, Cout), yc
 
