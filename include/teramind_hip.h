@@ -254,8 +254,9 @@ int tm_op_conv1_concat(const void* const* x_cb8, const int* cin, const int* coll
                        int dtype, int waves, void* stream);
 
 /* The block-input pass of the 16-bit modes on its own: th.cat of nsrc (1..3) sources (model/unet_ours.py:384,418) with
- * to_collage (:325-341) where collage[i] != 0, optional nearest x2 (Upsample, model/blocks.py:362-371; up2 != 0: sources at
- * S/2), LlamaRMSNorm over the real channel count c_real (model/MBAblocks.py:21-43; norm_w_dev: device fp32 [padded C], or
+ * to_collage (:325-341) where collage[i] != 0, optional resampling (up2 = 1: nearest x2, Upsample, model/blocks.py:362-371,
+ * sources at S/2; up2 = 2: the Downsample form of ResBlock(down=True), blocks.py:389-403 -- ONE plain source at 2S, every
+ * source voxel normalised and activated with its own statistics, then the 2 x 2 average; raw_h16 = the 2 x 2 average of x), LlamaRMSNorm over the real channel count c_real (model/MBAblocks.py:21-43; norm_w_dev: device fp32 [padded C], or
  * null), modulation (mod 0 none; 1 per image: device fp32 scale / shift rows [b][mod_stride], image = n / per_image,
  * apply_conditions :356-367; 2 per voxel: 16-bit CB8 scale / shift tensors of the output geometry with patch stride
  * mod_stride elements, modulate :608-614), SiLU (act != 0).  Sources and outputs are 16-bit CB8 DEVICE tensors (dtype

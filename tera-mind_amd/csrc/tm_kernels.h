@@ -196,7 +196,8 @@ hipError_t launch_conv_direct(const DirectLaunch& L, hipStream_t s);
 hipError_t launch_stem(const float* x, TV y, const float* w, const float* bias, int Cin, hipStream_t s,
                        uint16_t* y_h = nullptr, long yh_nstride = 0, int h_f16 = 0);
 // head: x CB8 (Cb blocks) -> y NCHW [N][Cout*Z][S][S]; w [9][x.Cb*8][8]
-hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s);
+// h16: 0 = x is fp32 CB8; 1 / 2 = x.p points at a bf16 / fp16 CB8 tensor of the same geometry (nstride in elements)
+hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s, int h16 = 0);
 
 // ---- layout converters ----------------------------------------------------------------
 hipError_t launch_to_cb8(const float* x, TV y, hipStream_t s);        // NCDHW -> CB8 (zero pads)

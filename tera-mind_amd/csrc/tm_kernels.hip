@@ -957,6 +957,111 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
   }
 }
 
+// Downsample form (ResBlock(down=True), model/MBAblocks.py:254-258, blocks.py:389-403: norm -> SiLU at full resolution, then
+// the 2 x 2 average of h and of x): an output voxel gathers its four source voxels, each normalised with its OWN statistics;
+// out = mean of the four activated values, raw = mean of the four inputs (the block's residual).  Four waves split the channel
+// blocks of 64 output voxels (C <= 256: 8 blocks x 4 sources x 16 bytes resident per lane).
+template <int NB, bool F16>
+__global__ __launch_bounds__(256) void prep_down_h16_kernel(PrepArgs pa) {
+  const PrepLaunch& L = pa.L;
+  __shared__ float red[4][4][64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int S = L.S, Z = L.Z, Ss = 2 * S;
+  const int vpn = Z * S * S;
+  const long vidx = (long)blockIdx.x * 64 + lane;
+  const bool valid = vidx < (long)vpn * L.N;
+  int n = 0, z = 0, y = 0, x = 0;
+  if (valid) {
+    n = (int)(vidx / vpn);
+    int rem = (int)(vidx - (long)n * vpn);
+    z = rem / (S * S); rem -= z * S * S;
+    y = rem / S; x = rem - y * S;
+  }
+  const long splane = (long)Z * Ss * Ss * 8;
+  const uint16_t* sp = (const uint16_t*)L.src[0].p + (long)n * L.src[0].nstride;
+  long soff[4];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) soff[sub] = ((long)(z * Ss + 2 * y + (sub >> 1)) * Ss + 2 * x + (sub & 1)) * 8;
+  const int cbtot = L.src[0].Cb;
+  pu32x4 c[NB][4];
+  float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int gb = wv + 4 * i;
+      if (gb < cbtot) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) c[i][sub] = *(const pu32x4*)(sp + soff[sub] + (long)gb * splane);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (wv + 4 * i < cbtot) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          float f[8];
+          unpack8<F16>(c[i][sub], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ssq[sub] += f[j] * f[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) red[wv][sub][lane] = ssq[sub];
+  __syncthreads();
+  if (!valid) return;
+  float rstd[4];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const float t = red[0][sub][lane] + red[1][sub][lane] + red[2][sub][lane] + red[3][sub][lane];
+    rstd[sub] = L.norm_w ? 1.0f / sqrtf(t * L.inv_c + TM_EPS) : 1.0f;
+  }
+  const long oplane = (long)vpn * 8;
+  const long oin = ((long)(z * S + y) * S + x) * 8;
+  uint16_t* const outp = L.out_h + (long)n * L.out_h_nstride + oin;
+  uint16_t* const rawp = L.raw_h ? L.raw_h + (long)n * L.raw_h_nstride + oin : nullptr;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int gb = wv + 4 * i;
+    if (gb < cbtot) {
+      float wn[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wn[j] = 1.f;
+      if (L.norm_w) {
+        const f32x4 w0 = *(const f32x4*)(L.norm_w + gb * 8), w1 = *(const f32x4*)(L.norm_w + gb * 8 + 4);
+        wn[0] = w0[0]; wn[1] = w0[1]; wn[2] = w0[2]; wn[3] = w0[3]; wn[4] = w1[0]; wn[5] = w1[1]; wn[6] = w1[2]; wn[7] = w1[3];
+      }
+      float o[8], r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[j] = 0.f; r[j] = 0.f; }
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        float v[8];
+        unpack8<F16>(c[i][sub], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          r[j] += v[j];
+          float t = L.norm_w ? wn[j] * (v[j] * rstd[sub]) : v[j];
+          if (L.act) t = t * __frcp_rn(1.0f + __expf(-t));
+          o[j] += t;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[j] *= 0.25f; r[j] *= 0.25f; }
+      *(pu32x4*)(outp + (long)gb * oplane) = pack8<F16>(o);
+      if (rawp) *(pu32x4*)(rawp + (long)gb * oplane) = pack8<F16>(r);
+    }
+  }
+  if (L.pad_blocks && wv == 0) {
+    for (int pb = 0; pb < L.pad_blocks; ++pb) {
+      *(pu32x4*)(outp + (long)(cbtot + pb) * oplane) = pu32x4{0u, 0u, 0u, 0u};
+      if (rawp) *(pu32x4*)(rawp + (long)(cbtot + pb) * oplane) = pu32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
 // variant: 0 = automatic, 1 = prep_kernel (the generic form), 2 = prep_h16_kernel with one wave per 64 voxels, 3 = prep_h16_kernel
 // with the four waves of a workgroup splitting the channel blocks
 static int g_prep_variant = 0;
@@ -991,6 +1096,14 @@ static bool launch_prep_h16(const PrepLaunch& L, hipStream_t s, int variant) {
 hipError_t launch_prep(const PrepLaunch& L, hipStream_t s) {
   static const int env_form = getenv("TM_PREP_FORM") ? atoi(getenv("TM_PREP_FORM")) : 0;       // A/B timing only
   const int form = g_prep_variant ? g_prep_variant : env_form;
+  if (form != 1 && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample == RS_DOWN2 && L.nsrc == 1 &&
+      !L.src[0].collage && L.mod == MOD_NONE && L.src[0].Cb <= 32) {
+    PrepArgs pa; pa.L = L;
+    const unsigned grid = (unsigned)(((long)L.N * L.Z * L.S * L.S + 63) / 64);
+    if (L.h_f16) hipLaunchKernelGGL((prep_down_h16_kernel<8, true>), dim3(grid), dim3(256), 0, s, pa);
+    else hipLaunchKernelGGL((prep_down_h16_kernel<8, false>), dim3(grid), dim3(256), 0, s, pa);
+    return hipGetLastError();
+  }
   if (form != 1 && L.src_h && L.out_h && !L.out && !L.raw && !L.drop_mask && L.resample != RS_DOWN2 &&
       (L.mod != MOD_VOXEL || L.mod_scale_h)) {
     if (L.h_f16 ? launch_prep_h16<true>(L, s, form) : launch_prep_h16<false>(L, s, form)) return hipGetLastError();
@@ -1171,6 +1284,9 @@ struct HeadArgs {
   float* y; const float* w; const float* bias;                    // w: [tap 9][ci][8]
   int N, Cout, Z, S;
 };
+// H16: 0 = fp32 CB8 input, 1 = bf16, 2 = fp16 (the 16-bit modes hand the normalised, activated tensor over in 16 bits like
+// every other conv input: half the bytes of the 9-tap gather)
+template <int H16>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   const int S = a.S;
   const long vpn = (long)a.Z * S * S;
@@ -1183,21 +1299,35 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const float* xb = a.x + (long)n * a.x_nstride;
+  const float* xb = a.x + (long)n * a.x_nstride;                   // H16: the same offsets count 16-bit elements
+  const uint16_t* xbh = (const uint16_t*)a.x + (long)n * a.x_nstride;
   // channel block outermost: the 9 taps of one block touch 3 rows of one plane back to back (L1 hits); with the
   // taps outermost every tap strides through all Cb planes and the rows are evicted before the next tap returns
   // to them (measured: 8.7x the input bytes fetched from HBM)
   for (int cb = 0; cb < a.Cb; ++cb) {
-    const float* xc = xb + (long)cb * vpn * 8;
+    const long co = (long)cb * vpn * 8;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int yi = y + ky - 1, xi = x + kx - 1;
         if (yi < 0 || yi >= S || xi < 0 || xi >= S) continue;
-        const float* xp = xc + ((long)(z * S + yi) * S + xi) * 8;
-        const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 4);
-        const float xv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const long eo = co + ((long)(z * S + yi) * S + xi) * 8;
+        float xv[8];
+        if (H16 == 0) {
+          const f32x4 a0 = *(const f32x4*)(xb + eo), a1 = *(const f32x4*)(xb + eo + 4);
+          xv[0] = a0[0]; xv[1] = a0[1]; xv[2] = a0[2]; xv[3] = a0[3]; xv[4] = a1[0]; xv[5] = a1[1]; xv[6] = a1[2]; xv[7] = a1[3];
+        } else if (H16 == 1) {
+          typedef __bf16 bf16x8_i __attribute__((ext_vector_type(8)));
+          const bf16x8_i v = *(const bf16x8_i*)(xbh + eo);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[c] = (float)v[c];
+        } else {
+          typedef _Float16 f16x8_i __attribute__((ext_vector_type(8)));
+          const f16x8_i v = *(const f16x8_i*)(xbh + eo);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[c] = (float)v[c];
+        }
         const float* wp = a.w + ((long)(ky * 3 + kx) * a.Cb + cb) * 64;
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -1209,11 +1339,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   for (int j = 0; j < a.Cout; ++j)
     a.y[(((long)n * a.Cout + j) * a.Z + z) * S * S + (long)y * S + x] = acc[j] + a.bias[j];
 }
-hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s) {
-  if (Cout > 8) return hipErrorInvalidValue;
+hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s, int h16) {
+  if (Cout > 8 || h16 < 0 || h16 > 2) return hipErrorInvalidValue;
   HeadArgs a{x.p, x.nstride, x.Cb, y, w, bias, x.N, Cout, x.Z, x.H};
   const long vox = (long)x.N * x.Z * x.H * x.W;
-  hipLaunchKernelGGL(head_kernel, dim3((unsigned)((vox + 255) / 256)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)((vox + 255) / 256));
+  if (h16 == 0) hipLaunchKernelGGL(head_kernel<0>, grid, dim3(256), 0, s, a);
+  else if (h16 == 1) hipLaunchKernelGGL(head_kernel<1>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(head_kernel<2>, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

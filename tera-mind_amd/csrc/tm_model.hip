@@ -1378,17 +1378,19 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
       if (col) { const std::string& p0 = m->res[e.ops[0].idx].pfx; dump_tv(cx, p0.substr(0, p0.size() - 2), hd); }
     }
     // head: RMSNorm -> SiLU -> Conv3d(1,3,3) -> 'b s z h w -> b (s z) h w'  (unet_ours.py:271-275,423-424)
-    TV A = cx.tensor(N, c.net_ch, Z, ps);
+    // (16-bit modes: the normalised, activated tensor is a 16-bit tensor like every other conv input)
+    TV A = cx.tensor_s(N, c.net_ch, Z, ps);
     if (!cx.dry) {
       PrepLaunch P;
       P.nsrc = 1;
       P.src[0].p = hd.p; P.src[0].nstride = hd.nstride; P.src[0].Cb = hd.Cb;
       P.src_h = h16 ? 1 : 0; P.h_f16 = c.dtype == TM_DTYPE_F16;
       P.N = N; P.Z = Z; P.S = ps; P.norm_w = m->out_norm; P.inv_c = 1.0f / (float)c.net_ch; P.act = 1; P.per_image = per;
-      P.out = A.p; P.out_nstride = A.nstride;
+      if (h16) { P.out_h = (uint16_t*)A.p; P.out_h_nstride = A.nstride; }
+      else { P.out = A.p; P.out_nstride = A.nstride; }
       cx.check(launch_prep(P, cx.s));
     }
-    if (!cx.dry) cx.check(launch_head(A, outp, m->head.w, m->head.bias, c.n_stain, cx.s));
+    if (!cx.dry) cx.check(launch_head(A, outp, m->head.w, m->head.bias, c.n_stain, cx.s, h16 ? (c.dtype == TM_DTYPE_F16 ? 2 : 1) : 0));
     cx.top = mark;
   };
   decode(true, pred);
@@ -1780,8 +1782,10 @@ extern "C" int tm_op_prep_h16(const void* const* src_h16, const int* src_c, cons
   for (int i = 0; i < nsrc; ++i) any_col = any_col || collage[i];
   const int q = any_col ? (p1 - 1) * (p2 - 1) : 1;
   if (any_col && (p1 < 2 || p2 < 2 || N % q)) return fail(TM_ERR_ARG, "collage needs N = b * (p1-1) * (p2-1)");
-  if (up2 && (any_col || (S & 1))) return fail(TM_ERR_ARG, "up2 takes plain sources and an even S");
-  const int Ss = up2 ? S / 2 : S;
+  if (up2 < 0 || up2 > 2) return fail(TM_ERR_ARG, "up2: 0 same, 1 nearest x2, 2 = 2 x 2 average (Downsample)");
+  if (up2 == 1 && (any_col || (S & 1))) return fail(TM_ERR_ARG, "up2 takes plain sources and an even S");
+  if (up2 == 2 && (any_col || nsrc != 1 || mod != MOD_NONE)) return fail(TM_ERR_ARG, "the downsample form takes one plain source, no modulation");
+  const int Ss = up2 == 1 ? S / 2 : (up2 == 2 ? 2 * S : S);
   PrepLaunch P;
   P.nsrc = nsrc;
   int cbtot = 0;
@@ -1793,7 +1797,7 @@ extern "C" int tm_op_prep_h16(const void* const* src_h16, const int* src_c, cons
   }
   const int cbe = (cbtot + 1) / 2 * 2;
   P.src_h = 1; P.h_f16 = dtype == TM_DTYPE_F16;
-  P.resample = up2 ? RS_UP2 : RS_SAME; P.N = N; P.Z = Z; P.S = S; P.p1 = p1; P.p2 = p2;
+  P.resample = up2 == 1 ? RS_UP2 : (up2 == 2 ? RS_DOWN2 : RS_SAME); P.N = N; P.Z = Z; P.S = S; P.p1 = p1; P.p2 = p2;
   P.norm_w = (const float*)norm_w_dev; P.inv_c = 1.0f / (float)c_real; P.act = act; P.per_image = per_image > 0 ? per_image : 1;
   P.mod = mod; P.mod_stride = mod_stride;
   if (mod == MOD_IMAGE) { P.mod_scale = (const float*)mod_scale; P.mod_shift = (const float*)mod_shift; }

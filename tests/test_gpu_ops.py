@@ -336,6 +336,26 @@ def test_conv27_16bit_residual_at_half_resolution(dtype):
     assert torch.equal(got.cpu(), ref), util.report("conv27 half-resolution residual " + dtype, got, ref)
 
 
+@pytest.mark.parametrize("C_,S", [(64, 32), (128, 16), (256, 8), (40, 8)])
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_prep_h16_downsample_form_vs_torch(C_, S, variant, dtype):
+    """ResBlock(down=True) input (model/MBAblocks.py:254-258, blocks.py:389-403): LlamaRMSNorm -> SiLU at full resolution,
+    then the 2 x 2 average of the activated tensor and (raw) of x itself; the 16-bit kernel and the generic one."""
+    td = util.H16[dtype][1]
+    g = torch.Generator().manual_seed(11)
+    N = 3
+    x = (torch.randn((N, C_, 2, 2 * S, 2 * S), generator=g) * 1.5).to(td).float()
+    w = torch.randn((C_,), generator=g) * 0.3 + 1.0
+    h = F.silu(w[None, :, None, None, None] * (x * torch.rsqrt(x.pow(2).mean(1, keepdim=True) + 1e-6)))
+    pool = lambda t: F.avg_pool3d(t, (1, 2, 2))
+    got, raw, _ = util.prep_h16([x.to(DEV)], (C_,), (0,), N, 2, 2, S, up2=2, norm_w=[w], act=True, dtype=dtype, variant=variant,
+                                want_raw=True)
+    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    for t, r in ((got[0].cpu(), pool(h)), (raw[0].cpu(), pool(x))):
+        assert bool(((t - r).abs() <= ulp * r.abs() + 1e-6).all()), util.report(f"prep down {dtype} v{variant}", t, r)
+
+
 def test_conv27_bf16_random_vs_bf16_rounded_reference():
     g = torch.Generator().manual_seed(17)
     N, Cin, Cout, S = 2, 741, 512, 8

@@ -197,7 +197,7 @@ def prep_h16(xs, cins, flags, b, p1, p2, S, up2=False, norm_w=None, mod=0, scale
     cin = (C.c_int * len(xc))(*cins)
     col = (C.c_int * len(xc))(*[int(f) for f in flags])
     ms = C.c_float(0.0)
-    _lib.check(_lib.lib().tm_op_prep_h16(ptrs, cin, col, len(xc), N, Z, S, p1, p2, int(up2), _lib.ptr(nw), sum(cins), mod,
+    _lib.check(_lib.lib().tm_op_prep_h16(ptrs, cin, col, len(xc), N, Z, S, p1, p2, int(up2), _lib.ptr(nw), sum(cins), mod,   # up2: 0 | 1 | 2 (down)
                                          _lib.ptr(sc), _lib.ptr(sh), stride, per_image, int(act), H16[dtype][0], variant,
                                          _lib.ptr(out), _lib.ptr(raw), iters, C.byref(ms), _lib.current_stream_ptr()),
                "tm_op_prep_h16")
