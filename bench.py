@@ -162,7 +162,8 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     res = launch.run_sweep(cfg, smp, model, genes, hnm=args.sweep_hnm, wnm=args.sweep_wnm, total_epochs=T, steps=steps,
                            warmup=warmup, device=dev, batch_tiles=args.sweep_batch_tiles, init="device", state="fp16",
                            on_step=on_step, after_warmup=lambda: model.profile(True), share_halo=share,
-                           batch_rows=args.sweep_batch_rows if share else 1, prefetch_genes=not share)
+                           batch_rows=args.sweep_batch_rows if share else 1, prefetch_genes=not share,
+                           cache_level0=bool(args.sweep_cache_level0))
     prof = model.profile_collect()
     model.profile(False)
     st = res["sweep"].local_state()
@@ -188,6 +189,9 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
            # one window per call: the patch columns neighbouring tiles share go through the encoder once (bit-identical for
            # gene tiles that agree where they overlap)
            "share_halo": share,
+           # level 0 of the RNA conditioning (gene attention -> down_z) kept per model call from the first step of the sweep on (the
+           # warm-up step here): the timed steps are steps 2 .. T of a sweep, the first one costs ~2.5 % more
+           "cache_level0": bool(args.sweep_cache_level0),
            "s_per_tile_step_per_gpu": round(res["dt"] / steps / max(1, -(-args.sweep_hnm // world) * args.sweep_wnm), 5),
            "world_size_rccl": res["world"], "backend": res["backend"],
            "exchange_ms_per_step": round(res["exchange_ms_per_step"], 3),
@@ -341,6 +345,8 @@ def main():
     ap.add_argument("--sweep-dtype", choices=["bf16", "f16", "f32"], default="bf16")
     ap.add_argument("--sweep-batch-tiles", type=int, default=8, help="tiles of a tile row per model call")
     ap.add_argument("--sweep-batch-rows", type=int, default=2, help="tile rows per model call (shared-halo windows only)")
+    ap.add_argument("--sweep-cache-level0", type=int, default=1,
+                    help="1: keep level 0 of the RNA conditioning of every model call across the diffusion steps (59 KB per patch)")
     ap.add_argument("--sweep-share-halo", type=int, default=1,
                     help="1: the tiles of a call form one window (shared encoder patch columns computed once); 0: stacked tiles")
     ap.add_argument("--rehearse", action="store_true",

@@ -122,6 +122,21 @@ int tm_unet_forward_rna(tm_model* m, const void* x, const int64_t* t, const void
                         int b, int p1, int p2, void* pred, void* pred2_or_null, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* The tile sweep (mode B, test_brn.py:232-255) also recomputes the conditioning of the SAME genes at each of its T diffusion
+ * steps, but the whole pyramid of a tile (~1 MB per patch) is too large to keep for every tile.  Level 0 -- gene-gene
+ * attention -> down_z -> Upsample (model/unet_ours.py:298-310, MBAblocks.py:472-479), the part that reads the gene counts and
+ * costs most -- is 59 KB per patch: a caller may keep it per tile / window and skip that part (and the dense gene tensor)
+ * from the second step on:
+ *   tm_rna_level0_bytes     size of the level-0 tensor for (b, p1, p2) (the activation-stream type of the model: fp32 or 16-bit)
+ *   tm_rna_level0           rna_dense -> level0 (16-byte aligned device buffer); workspace >= tm_workspace_bytes(.., 0)
+ *   tm_unet_forward_level0  tm_unet_forward with level0 in place of rna_dense; bit-identical results. */
+size_t tm_rna_level0_bytes(const tm_model* m, int b, int p1, int p2);
+int tm_rna_level0(tm_model* m, const void* rna_dense, int b, int p1, int p2, void* level0, size_t level0_bytes,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int tm_unet_forward_level0(tm_model* m, const void* x, const int64_t* t, const void* level0, size_t level0_bytes,
+                           int b, int p1, int p2, void* pred, void* pred2_or_null, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Per-step scalar coefficients: the float64 tables of GaussianDiffusionBeatGans.__init__
  * (diffusion/base.py:64-109) gathered at index i and cast `.float()` (base.py:643) by
  * the host. */

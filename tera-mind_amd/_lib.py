@@ -48,6 +48,9 @@ SIGNATURES = {
     "tm_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
     "tm_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tm_rna_level0_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "tm_rna_level0": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "tm_unet_forward_level0": (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 3 + [c_void_p] * 3 + [c_size_t, c_void_p]),
     "tm_rna_pyramid_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "tm_rna_pyramid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "tm_unet_forward_rna": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,

@@ -36,7 +36,7 @@ class TileSweep:
                  hst: int = 256, wst: int = 256, hnm: int = 32, wnm: int = 32, total_epochs: int = 15,
                  total_slc: int = 50, device="cpu", rank: int = 0, world: int = 1, batch_tiles: int = 1,
                  group=None, init: str = "reference", noise_provider: Optional[Callable] = None,
-                 state: str = "fp32x2", share_halo: bool = False, batch_rows: int = 1):
+                 state: str = "fp32x2", share_halo: bool = False, batch_rows: int = 1, cache_level0: bool = False):
         """hst/wst/hnm/wnm/total_epochs mirror the test_brn CLI (test_brn.py:302-334).
         gene_provider(row, col) -> dense [20, 20, (total_slc + 2*zpad) * 500] gene tile (already
         block-summed and z-padded like MBADataset_tst._getgene/_pad_gn) for ABSOLUTE tile
@@ -60,7 +60,12 @@ class TileSweep:
                utils/MBADataset_tst.py:65-91; `consistent_gene_provider` has that property, a per-tile seeded
                provider does not).  The window's genes: every tile's own 16 x 16 interior cells, the outer halo
                cells from the window's edge tiles.  batch_rows (share_halo only): tile rows per window -- the halo
-               ROWS between them are shared the same way ((4 r + 1) x (4 k + 1) encoder patches for r x k tiles)."""
+               ROWS between them are shared the same way ((4 r + 1) x (4 k + 1) encoder patches for r x k tiles).
+        cache_level0: keep level 0 of the RNA conditioning (gene attention -> down_z -> Upsample, unet_ours.py:298-310: the
+               part that reads the gene counts) of every model call of a step and reuse it in the following steps -- the
+               genes of a tile are the same at each of the T steps (test_brn.py:232-255 re-reads and re-embeds them every
+               step).  59 KB per encoder patch (37 MB per tile, 27 MB with 4 x 4 shared-halo windows): an ROI-scale option,
+               not a whole-brain one.  Bit-identical (model.precompute_rna_level0 / tm_unet_forward_level0)."""
         if state not in ("fp32x2", "fp16"):
             raise ValueError(f"state {state!r}")
         self.state = state
@@ -78,6 +83,8 @@ class TileSweep:
         self.batch_tiles, self.init, self.noise_provider = batch_tiles, init, noise_provider
         self.share_halo = bool(share_halo)
         self.batch_rows = max(1, int(batch_rows)) if self.share_halo else 1
+        self.cache_level0 = bool(cache_level0) and hasattr(model, "precompute_rna_level0")
+        self._level0 = {}
         self.r0, self.r1 = tiles.row_block_partition(hnm, world)[rank]
         self.nrows = self.r1 - self.r0
         H = self.nrows * tiles.TILE + 2 * PAD
@@ -217,21 +224,36 @@ class TileSweep:
         else:
             y = lr * tiles.TILE
             win = self.cur[:, y:y + nr * tiles.TILE + 2 * PAD, x0:x0 + wpx]
-        blk = conf.patch_size // conf.gn_sz                                   # pixels per gene cell
-        hc, ic = PAD // blk, tiles.TILE // blk                               # halo / interior cells per tile side
-        bands = []
-        for i in range(nr):                                                   # one band of cell rows per tile row
-            gts = [self.gene(self.row0 + self.r0 + lr + i, self.col0 + c0 + j).to(self.dev) for j in range(k)]
-            band = torch.cat([gts[0][:, :hc]] + [g[:, hc:hc + ic] for g in gts] + [gts[-1][:, hc + ic:]], dim=1)
-            r0 = 0 if i == 0 else hc                                          # outer halo rows from the window's edge tiles
-            r1 = hc + ic + (hc if i == nr - 1 else 0)
-            bands.append(band[r0:r1])
-        rna_hwc = torch.cat(bands, dim=0)[None]
-        x, rna, shape = tiles.run_batch_inputs(win.permute(1, 2, 0)[None], rna_hwc, conf.patch_size, conf.gn_sz,
-                                               self.total_slc, conf.rna_slc)
+        ps = conf.patch_size
+        xz = tiles.zchunk_state(win.permute(1, 2, 0)[None], self.total_slc, conf.rna_slc)
+        shape = (xz.shape[0], xz.shape[3], xz.shape[1] - ps, xz.shape[2] - ps)
+        x = tiles.patchify_hwc(xz, ps, True)
+        key = ("w", lr, c0, nr, k)
+        rna = self._level0.get(key)
+        if rna is None:
+            blk = ps // conf.gn_sz                                            # pixels per gene cell
+            hc, ic = PAD // blk, tiles.TILE // blk                           # halo / interior cells per tile side
+            bands = []
+            for i in range(nr):                                               # one band of cell rows per tile row
+                gts = [self.gene(self.row0 + self.r0 + lr + i, self.col0 + c0 + j).to(self.dev) for j in range(k)]
+                band = torch.cat([gts[0][:, :hc]] + [g[:, hc:hc + ic] for g in gts] + [gts[-1][:, hc + ic:]], dim=1)
+                r0 = 0 if i == 0 else hc                                      # outer halo rows from the window's edge tiles
+                r1 = hc + ic + (hc if i == nr - 1 else 0)
+                bands.append(band[r0:r1])
+            rna = tiles.patchify_hwc(tiles.zchunk_rna(torch.cat(bands, dim=0)[None], conf.rna_slc), conf.gn_sz, False)
+            rna = self._remember_level0(key, rna, shape)
         out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
-                                  patch_size=conf.patch_size, idx=self.T - epoch - 1, model_kwargs=None)
+                                  patch_size=ps, idx=self.T - epoch - 1, model_kwargs=None)
         return tiles.regroup_output(out, 1, self.n_stain)[0]
+
+    def _remember_level0(self, key, rna, shape):
+        """cache_level0: level 0 of the RNA conditioning of this call's genes, kept for the following steps."""
+        if not self.cache_level0:
+            return rna
+        l0 = self.model.precompute_rna_level0(rna, shape[0], imgs=torch.empty(tuple(shape), device="meta"),
+                                              patch_size=self.conf.patch_size)
+        self._level0[key] = l0
+        return l0
 
     def run_batch(self, tile_list, epoch: int):
         """Tester._run_batch (test_brn.py:174-226) for a list of (local_row, col) tiles."""
@@ -256,8 +278,16 @@ class TileSweep:
                     self.nxt[:, y:y + tiles.TILE, PAD + x0:PAD + x1].copy_(o.half().float())
             return
         tile_hwc = torch.stack([self._window(lr, c) for lr, c in tile_list])
-        rna_hwc = torch.stack([self.gene(self.row0 + self.r0 + lr, self.col0 + c).to(self.dev) for lr, c in tile_list])
-        x, rna, shape = tiles.run_batch_inputs(tile_hwc, rna_hwc, conf.patch_size, conf.gn_sz, self.total_slc, conf.rna_slc)
+        key = ("t",) + tuple(tile_list)
+        rna = self._level0.get(key)
+        if rna is None:
+            rna_hwc = torch.stack([self.gene(self.row0 + self.r0 + lr, self.col0 + c).to(self.dev) for lr, c in tile_list])
+            x, rna, shape = tiles.run_batch_inputs(tile_hwc, rna_hwc, conf.patch_size, conf.gn_sz, self.total_slc, conf.rna_slc)
+            rna = self._remember_level0(key, rna, shape)
+        else:
+            xz = tiles.zchunk_state(tile_hwc, self.total_slc, conf.rna_slc)
+            shape = (xz.shape[0], xz.shape[3], xz.shape[1] - conf.patch_size, xz.shape[2] - conf.patch_size)
+            x = tiles.patchify_hwc(xz, conf.patch_size, True)
         out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
                                   patch_size=conf.patch_size, idx=self.T - epoch - 1, model_kwargs=None)
         out = tiles.regroup_output(out, len(tile_list), self.n_stain)

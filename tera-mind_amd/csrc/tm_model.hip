@@ -1185,18 +1185,25 @@ struct RnaOut { TV rl[4]; TV rs[3]; };
 
 // Allocates the persistent outputs FIRST (so that their layout inside a caller-provided pyramid buffer is a pure function
 // of (b, p1, p2)), computes them, and releases the scratch.  rna == nullptr: layout only.
-static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
+// l0_in: level 0 (gene attention -> down_z -> Upsample, the part that reads the gene counts) was computed before
+// (tm_rna_level0) and is taken from that buffer -- a tile sweep recomputes the conditioning of the SAME genes at every diffusion
+// step (test_brn.py:232-255), and level 0 is both its costly part and small enough to keep (59 KB per patch).
+// l0_out: compute level 0 only, into that buffer.
+static void rna_stage(Ctx& cx, const float* rna, RnaOut& R, const void* l0_in = nullptr, void* l0_out = nullptr) {
   tm_model* m = cx.m;
   const tm_config& c = m->cfg;
   const int Z = m->z, Ne = cx.Ne;
-  const bool h16 = is_h16(c.dtype), run = !cx.dry && rna != nullptr;
+  const bool h16 = is_h16(c.dtype), run = !cx.dry && (rna != nullptr || l0_in != nullptr);
+  const bool head = l0_in == nullptr;                            // gene attention + down_z run in this call
   int S = m->gn * 2;
   for (int i = 0; i < 4; ++i) { R.rl[i] = cx.tensor_s(Ne, m->rw[i], Z, S); S *= 2; }
+  if (l0_in) R.rl[0].p = (float*)const_cast<void*>(l0_in);
+  if (l0_out) R.rl[0].p = (float*)l0_out;
   S = m->gn * 2;
   if (!h16) for (int i = 0; i < 3; ++i) { R.rs[i] = cx.tensor(Ne, m->rw[i], Z, S); S *= 2; }
   const size_t rna_mark = cx.top;
   TV tok = cx.tensor(Ne, c.rna_num, c.rna_slc, m->gn);           // gene-attention output, CB8 [Ne][Gb][zs][gn][gn][8]
-  if (run) {
+  if (run && head) {
     cx.check(hipMemsetAsync(tok.p, 0, (size_t)Ne * tok.nstride * sizeof(float), cx.s));      // pad gene slots
     if (m->gene_mfma)
       cx.check(launch_gene_attn(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->gene, tok.p, nullptr, 0, c.rna_slc, cx.s));
@@ -1204,7 +1211,7 @@ static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
   if (!m->gene_mfma) {
     const size_t mark = cx.top;
     float* gws = cx.alloc_f((size_t)Ne * gene_generic_split(Ne) * gene_generic_ws_floats(c.rna_num, m->D));
-    if (run)
+    if (run && head)
       cx.check(launch_gene_attn_generic(rna, Ne, m->gn, c.rna_slc, c.rna_num, m->D, m->gene, m->gene_idx, tok.p, nullptr, 0,
                                         c.rna_slc, gws, cx.s));
     cx.top = mark;                                               // scratch only (the stream orders its reuse)
@@ -1220,21 +1227,26 @@ static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
     const int h_f16 = c.dtype == TM_DTYPE_F16;
     int S0 = m->gn * 2;
     TV rl0 = cx.tensor(Ne, m->rw[0], Z, S0);
-    if (m->downz_mfma) run_conv(cx, tok, m->downz, rl0, nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
-    else {
-      const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl0);
-      if (run) cx.check(hipMemsetAsync(rl0.p, 0, (size_t)Ne * rl0.nstride * sizeof(float), cx.s));     // pad channels
-      run_direct(cx, m->downz_d, tok.p, ax, rl0.p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+    if (head) {
+      if (m->downz_mfma) run_conv(cx, tok, m->downz, rl0, nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
+      else {
+        const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl0);
+        if (run) cx.check(hipMemsetAsync(rl0.p, 0, (size_t)Ne * rl0.nstride * sizeof(float), cx.s));     // pad channels
+        run_direct(cx, m->downz_d, tok.p, ax, rl0.p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+      }
+      if (run) {
+        PrepLaunch P;                                              // fp32 level 0 -> the 16-bit stream tensor
+        P.nsrc = 1;
+        P.src[0].p = rl0.p; P.src[0].nstride = rl0.nstride; P.src[0].Cb = rl0.Cb;
+        P.N = Ne; P.Z = Z; P.S = S0; P.h_f16 = h_f16;
+        P.out_h = (uint16_t*)R.rl[0].p; P.out_h_nstride = R.rl[0].nstride;
+        cx.check(launch_prep(P, cx.s));
+      }
     }
+    if (l0_out) { cx.dry = was_dry; cx.top = rna_mark; return; }
     const int cbe0 = (rl0.Cb + 1) / 2 * 2;
     TVH act = cx.tensor_h(Ne, cbe0, Z, S0);                        // SiLU(level) = the conv input (even block count)
     if (run) {
-      PrepLaunch P;                                                // fp32 level 0 -> the 16-bit stream tensor
-      P.nsrc = 1;
-      P.src[0].p = rl0.p; P.src[0].nstride = rl0.nstride; P.src[0].Cb = rl0.Cb;
-      P.N = Ne; P.Z = Z; P.S = S0; P.h_f16 = h_f16;
-      P.out_h = (uint16_t*)R.rl[0].p; P.out_h_nstride = R.rl[0].nstride;
-      cx.check(launch_prep(P, cx.s));
       PrepLaunch Q;                                                // SiLU of it, pair-padded
       Q.nsrc = 1; Q.src_h = 1; Q.h_f16 = h_f16;
       Q.src[0].p = R.rl[0].p; Q.src[0].nstride = R.rl[0].nstride; Q.src[0].Cb = R.rl[0].Cb;
@@ -1279,13 +1291,16 @@ static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
   }
   TV* rl = R.rl;
   TV* rs = R.rs;
-  if (m->downz_mfma) run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
-  else {
-    // generic (kz, gn): direct conv straight from / to the CB8 tensors, nearest x2 fused into the store
-    const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl[0]);
-    if (run) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));   // pad channels
-    run_direct(cx, m->downz_d, tok.p, ax, rl[0].p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+  if (head) {
+    if (m->downz_mfma) run_conv(cx, tok, m->downz, rl[0], nullptr, nullptr, EPI_UP2, 0, ZM_VALID);      // down_z + Upsample
+    else {
+      // generic (kz, gn): direct conv straight from / to the CB8 tensors, nearest x2 fused into the store
+      const Acc5 ax = acc_cb8(tok), ay = acc_cb8(rl[0]);
+      if (run) cx.check(hipMemsetAsync(rl[0].p, 0, (size_t)Ne * rl[0].nstride * sizeof(float), cx.s));   // pad channels
+      run_direct(cx, m->downz_d, tok.p, ax, rl[0].p, ay, Ne, c.rna_slc, Z, m->gn, 0, 0, 1);
+    }
   }
+  if (l0_out) { cx.dry = was_dry; cx.top = rna_mark; return; }
   for (int i = 1; i < 4; ++i) {
     if (run) {
       PrepLaunch P;
@@ -1303,7 +1318,7 @@ static void rna_stage(Ctx& cx, const float* rna, RnaOut& R) {
 
 // rna != nullptr: compute the conditioning inside this call's workspace; otherwise R_in (tm_rna_pyramid) is used
 static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* rna, const RnaOut* R_in, float* pred,
-                        float* pred2) {
+                        float* pred2, const void* l0_in = nullptr) {
   tm_model* m = cx.m;
   const tm_config& c = m->cfg;
   const int Z = m->z, L = m->L, ps = c.patch_size, Ne = cx.Ne, Nd = cx.Nd, b = cx.b;
@@ -1319,7 +1334,7 @@ static int forward_impl(Ctx& cx, const float* x, const int64_t* t, const float* 
   }
   // ---- RNA pyramid ----
   RnaOut Rloc;
-  if (!R_in) { rna_stage(cx, rna, Rloc); R_in = &Rloc; }
+  if (!R_in) { rna_stage(cx, rna, Rloc, l0_in); R_in = &Rloc; }
   TV rl[4], rs[3];
   for (int i = 0; i < 4; ++i) rl[i] = R_in->rl[i];
   for (int i = 0; i < 3; ++i) rs[i] = R_in->rs[i];
@@ -1461,6 +1476,56 @@ extern "C" int tm_rna_pyramid(tm_model* m, const void* rna_dense, int b, int p1,
   pyramid_ctx(cx, m, b, p1, p2, pyramid, pyramid_bytes, (hipStream_t)stream);
   RnaOut R;
   rna_stage(cx, (const float*)rna_dense, R);
+  if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
+  return TM_OK;
+}
+// ---- level 0 of the RNA conditioning on its own (the sweep's per-window cache) ----
+static TV level0_geom(const tm_model* m, int Ne) {
+  TV t;
+  t.N = Ne; t.C = m->rw[0]; t.Cb = (m->rw[0] + 7) / 8; t.Z = m->z; t.H = m->gn * 2; t.W = m->gn * 2;
+  t.nstride = (long)t.Cb * t.plane();
+  return t;
+}
+extern "C" size_t tm_rna_level0_bytes(const tm_model* m, int b, int p1, int p2) {
+  if (check_fwd_args(m, b, p1, p2) != TM_OK) return 0;
+  const TV t = level0_geom(m, b * p1 * p2);
+  return (size_t)t.N * t.nstride * (is_h16(m->cfg.dtype) ? 2 : 4);
+}
+static void plain_ctx(Ctx& cx, tm_model* m, int b, int p1, int p2, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  cx.m = m; cx.s = s;
+  cx.base = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+  cx.cap = workspace_bytes - (size_t)(cx.base - (char*)workspace);
+  cx.b = b; cx.p1 = p1; cx.p2 = p2; cx.Ne = b * p1 * p2; cx.Nd = b * (p1 - 1) * (p2 - 1);
+}
+extern "C" int tm_rna_level0(tm_model* m, const void* rna_dense, int b, int p1, int p2, void* level0, size_t level0_bytes,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_fwd_args(m, b, p1, p2);
+  if (rc != TM_OK) return rc;
+  if (!rna_dense || !level0 || !workspace) return fail(TM_ERR_ARG, "null tensor argument");
+  if (((uintptr_t)level0 & 15) != 0) return fail(TM_ERR_ARG, "level0 buffer must be 16-byte aligned");
+  if (level0_bytes < tm_rna_level0_bytes(m, b, p1, p2)) return fail(TM_ERR_WORKSPACE, "level-0 buffer too small for (b, p1, p2)");
+  const size_t need = tm_workspace_bytes(m, b, p1, p2, 0);
+  if (workspace_bytes < need) return fail(TM_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  Ctx cx;
+  plain_ctx(cx, m, b, p1, p2, workspace, workspace_bytes, (hipStream_t)stream);
+  RnaOut R;
+  rna_stage(cx, (const float*)rna_dense, R, nullptr, level0);
+  if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
+  return TM_OK;
+}
+extern "C" int tm_unet_forward_level0(tm_model* m, const void* x, const int64_t* t, const void* level0, size_t level0_bytes,
+                                      int b, int p1, int p2, void* pred, void* pred2_or_null, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  int rc = check_fwd_args(m, b, p1, p2);
+  if (rc != TM_OK) return rc;
+  if (!x || !t || !level0 || !pred || !workspace) return fail(TM_ERR_ARG, "null tensor argument");
+  if (((uintptr_t)level0 & 15) != 0) return fail(TM_ERR_ARG, "level0 buffer must be 16-byte aligned");
+  if (level0_bytes < tm_rna_level0_bytes(m, b, p1, p2)) return fail(TM_ERR_WORKSPACE, "level-0 buffer too small for (b, p1, p2)");
+  const size_t need = tm_workspace_bytes(m, b, p1, p2, pred2_or_null != nullptr);
+  if (workspace_bytes < need) return fail(TM_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, need);
+  Ctx cx;
+  plain_ctx(cx, m, b, p1, p2, workspace, workspace_bytes, (hipStream_t)stream);
+  forward_impl(cx, (const float*)x, t, nullptr, nullptr, (float*)pred, (float*)pred2_or_null, level0);
   if (cx.err != hipSuccess) return fail(TM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(cx.err));
   return TM_OK;
 }

@@ -211,7 +211,8 @@ class SpacedDiffusionBeatGans:
         P1, P2 = H // ps, W // ps
         indices = list(range(self.num_timesteps))[::-1] if idx is None else [idx]
         rna_msk = None
-        if torch.is_tensor(rna):
+        precomputed = hasattr(rna, "buf") and hasattr(rna, "p1")            # unet.RnaPyramid / unet.RnaLevel0: handed through
+        if torch.is_tensor(rna) or precomputed:
             rna_new = rna
         elif isinstance(rna, (tuple, list)) and len(rna) == 2:
             rna_new, rna_msk = rna
@@ -219,7 +220,7 @@ class SpacedDiffusionBeatGans:
             r_sz = ps // ((H + ps) // rna[2][1])                              # base.py:594
             rna_new = sparse_repatch(rna, r_sz)
         shape_only = torch.empty((b, c, H, W), device="meta")                 # model reads imgs.shape only
-        if len(indices) > 1 and hasattr(model, "precompute_rna"):
+        if len(indices) > 1 and hasattr(model, "precompute_rna") and not precomputed:
             # mode A: the genes are the same in every step of the reverse loop; the reference recomputes get_rna
             # (unet_ours.py:376) per step, here the conditioning pyramid is computed once (bit-identical results)
             rna_new = model.precompute_rna(rna_new, b, imgs=shape_only, patch_size=ps)

@@ -140,7 +140,35 @@ class RnaPyramid:
         self.buf, self.b, self.p1, self.p2 = buf, b, p1, p2
 
 
+class RnaLevel0:
+    """Level 0 of the RNA conditioning (gene attention -> down_z -> Upsample), computed once per tile / window of a sweep
+    (BeatGANsUNetModel.precompute_rna_level0) and handed to every diffusion step in place of the genes.  59 KB per patch."""
+
+    def __init__(self, buf: torch.Tensor, b: int, p1: int, p2: int):
+        self.buf, self.b, self.p1, self.p2 = buf, b, p1, p2
+
+
 class BeatGANsUNetModel(_HipModel):
+    def precompute_rna_level0(self, rna, b: int, imgs=None, patch_size=64) -> RnaLevel0:
+        """The part of get_rna (unet_ours.py:298-310) that reads the gene counts, for `b` images whose padded patch grid is
+        taken from `imgs.shape[-2:]`; pass the result as `rna=` to forward()."""
+        if not self._finalized:
+            raise RuntimeError("load_state_dict() must be called before precompute_rna_level0")
+        H, W = imgs.shape[-2:]
+        p1, p2 = H // patch_size + 1, W // patch_size + 1
+        rna_d = densify_rna(rna, self.device)
+        gn, zg = self.conf.gn_sz, self.conf.rna_slc * 500
+        if tuple(rna_d.shape) != (b * p1 * p2, gn, gn, zg):
+            raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(b * p1 * p2, gn, gn, zg)}")
+        with torch.cuda.device(self.device):
+            n = self._L.tm_rna_level0_bytes(self._h, b, p1, p2)
+            buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+            need = self._L.tm_workspace_bytes(self._h, b, p1, p2, 0)
+            ws = self._workspace(need)
+            _lib.check(self._L.tm_rna_level0(self._h, _lib.ptr(rna_d), b, p1, p2, _lib.ptr(buf), n, _lib.ptr(ws), ws.numel(),
+                                             _lib.current_stream_ptr()), "tm_rna_level0")
+        return RnaLevel0(buf, b, p1, p2)
+
     def precompute_rna(self, rna, b: int, imgs=None, patch_size=64) -> RnaPyramid:
         """get_rna (unet_ours.py:298-323) for `b` images whose padded patch grid is taken from `imgs.shape[-2:]`: depends
         on the genes only, so a T-step sampler calls it once and passes the result as `rna=` to every step."""
@@ -181,10 +209,10 @@ class BeatGANsUNetModel(_HipModel):
         C_ = self.conf.in_channels
         if tuple(x.shape) != (ne, C_, patch_size, patch_size):
             raise ValueError(f"x has shape {tuple(x.shape)}, expected {(ne, C_, patch_size, patch_size)}")
-        pyr = rna if isinstance(rna, RnaPyramid) else None
+        pyr = rna if isinstance(rna, (RnaPyramid, RnaLevel0)) else None
         if pyr is not None:
             if (pyr.b, pyr.p1, pyr.p2) != (b, p1, p2):
-                raise ValueError(f"RnaPyramid was computed for (b, p1, p2) = {(pyr.b, pyr.p1, pyr.p2)}, this call has {(b, p1, p2)}")
+                raise ValueError(f"{type(pyr).__name__} was computed for (b, p1, p2) = {(pyr.b, pyr.p1, pyr.p2)}, this call has {(b, p1, p2)}")
         else:
             rna_d = densify_rna(rna, self.device)
             gn, zg = self.conf.gn_sz, self.conf.rna_slc * 500
@@ -195,7 +223,11 @@ class BeatGANsUNetModel(_HipModel):
         with torch.cuda.device(self.device):
             need = self._L.tm_workspace_bytes(self._h, b, p1, p2, int(want_pred2))
             ws = self._workspace(need)
-            if pyr is not None:
+            if isinstance(pyr, RnaLevel0):
+                _lib.check(self._L.tm_unet_forward_level0(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(pyr.buf), pyr.buf.numel(), b, p1,
+                                                          p2, _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+                                                          _lib.current_stream_ptr()), "tm_unet_forward_level0")
+            elif pyr is not None:
                 _lib.check(self._L.tm_unet_forward_rna(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(pyr.buf), pyr.buf.numel(), b, p1, p2,
                                                        _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
                                                        _lib.current_stream_ptr()), "tm_unet_forward_rna")
@@ -234,4 +266,4 @@ def make_model(conf: PathConfig, device="cuda:0", state_dict=None, vis_only=Fals
     return m
 
 
-__all__ = ["AutoencReturn", "RnaPyramid", "BeatGANsUNetModel", "GeneAttnModel", "make_model", "param_spec"]
+__all__ = ["AutoencReturn", "RnaPyramid", "RnaLevel0", "BeatGANsUNetModel", "GeneAttnModel", "make_model", "param_spec"]

@@ -133,3 +133,24 @@ def test_share_halo_window_is_bit_identical_to_per_tile_calls(dtype, state):
     rows2 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=2, batch_rows=2, share_halo=True, **kw3).test()
     rows3 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, batch_rows=3, share_halo=True, **kw3).test()
     assert torch.equal(per_tile3, rows2) and torch.equal(per_tile3, rows3)
+
+
+@pytest.mark.parametrize("dtype,state", [("f32", "fp32x2"), ("bf16", "fp16")])
+def test_cached_level0_sweep_is_bit_identical(dtype, state):
+    """TileSweep(cache_level0=True): level 0 of the RNA conditioning (gene attention -> down_z -> Upsample,
+    unet_ours.py:298-310) of every model call is computed in the first step and reused in the following ones (the genes of
+    a tile do not change between steps, test_brn.py:232-255) -- the same states, bit for bit, for stacked tiles and for
+    shared-halo windows."""
+    from teramind_amd.brain import consistent_gene_provider
+    cfg = PathConfig(compute_dtype=dtype)
+    model = BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    genes = consistent_gene_provider(cfg, DEV, total_slc=SLC, density=0.05)
+    T3 = 3
+    kw = dict(hst=512, wst=1024, hnm=2, wnm=2, total_epochs=T3, total_slc=SLC, device=DEV, init="device", state=state)
+    mk = lambda **k: TileSweep(cfg, SpacedDiffusionBeatGans(T3, "ddim"), model, genes, **kw, **k)
+    plain = mk(batch_tiles=2).test()
+    sw = mk(batch_tiles=2, cache_level0=True)
+    cached = sw.test()
+    assert len(sw._level0) == 2 and torch.equal(plain, cached)
+    win = mk(batch_tiles=2, batch_rows=2, share_halo=True, cache_level0=True).test()
+    assert torch.equal(plain, win)
