@@ -43,18 +43,22 @@ def gene_provider(row, col):
     return (torch.rand((20, 20, (SLC + 2) * 500), generator=g) < 0.01).float()
 
 
-def make_sweep(rank, world, state="fp32x2", batch_tiles=2):
-    return TileSweep(PathConfig(), StandInSampler(), None, gene_provider, hst=512, wst=768, hnm=HNM, wnm=WNM,
+def make_sweep(rank, world, state="fp32x2", batch_tiles=2, share=False):
+    genes = gene_provider
+    if share:                 # shared-halo windows need gene tiles that agree where they overlap
+        from teramind_amd.brain import consistent_gene_provider
+        genes = consistent_gene_provider(PathConfig(), "cpu", total_slc=SLC, density=0.01)
+    return TileSweep(PathConfig(), StandInSampler(), None, genes, hst=512, wst=768, hnm=HNM, wnm=WNM,
                      total_epochs=T, total_slc=SLC, device="cpu", rank=rank, world=world, batch_tiles=batch_tiles,
-                     state=state)
+                     state=state, share_halo=share)
 
 
-def _worker(rank, world, port, q, state="fp32x2"):
+def _worker(rank, world, port, q, state="fp32x2", share=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sw = make_sweep(rank, world, state)
+        sw = make_sweep(rank, world, state, share=share)
         out = sw.test().float().clone()
         q.put((rank, sw.r0, sw.r1, out.numpy()))     # by value: the worker may exit before the parent reads
         dist.barrier()
@@ -70,16 +74,19 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,state", [(2, "fp32x2"), (3, "fp32x2"), (2, "fp16")])
-def test_row_sharded_sweep_equals_single_rank(world, state):
+@pytest.mark.parametrize("world,state,share", [(2, "fp32x2", False), (3, "fp32x2", False), (2, "fp16", False), (2, "fp16", True)])
+def test_row_sharded_sweep_equals_single_rank(world, state, share):
+    """share: one-row shared-halo windows (TileSweep(share_halo=True)) -- the same windows whatever the row partition, so
+    the row-sharded result still equals the single-rank one (the stand-in model is not patch-local, hence no comparison
+    with per-tile calls here: that equality is tests/test_gpu_sweep.py's, on the real model)."""
     torch.set_num_threads(4)
-    ref = make_sweep(0, 1).test()
+    ref = make_sweep(0, 1, share=share).test()
     assert ref.shape == (SLC * 2, HNM * 256, WNM * 256)
     assert float(ref.abs().max()) <= 1.0 + 1e-6 and float(ref.std()) > 0.05
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, state)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, state, share)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
