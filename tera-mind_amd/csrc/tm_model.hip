@@ -109,6 +109,8 @@ struct tm_model {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
   double prof_nominal = 0, prof_bytes = 0;
+  struct ProfTag { int cin, cout, S, N; double nominal; };
+  std::vector<ProfTag> prof_tag;     // per counted launch (TM_PROF_LAYERS)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -646,11 +648,18 @@ extern "C" int tm_profile_collect(tm_model* m, tm_prof_stats* out) {
   if (!m || !out) return fail(TM_ERR_ARG, "null argument");
   memset(out, 0, sizeof(*out));
   if (m->prof_used) HIP_TRY(hipEventSynchronize(m->prof_ev[m->prof_used - 1].second));
+  // TM_PROF_LAYERS=<file>: one line per counted launch (diagnosis: which layers sit furthest below the kernel's average)
+  static const char* layer_log = getenv("TM_PROF_LAYERS");
+  FILE* lf = (layer_log && m->prof_tag.size() == m->prof_used) ? fopen(layer_log, "a") : nullptr;
   for (size_t i = 0; i < m->prof_used; ++i) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, m->prof_ev[i].first, m->prof_ev[i].second));
     out->total_ms += ms;
+    if (lf) fprintf(lf, "%zu cin %d cout %d S %d N %d nominal_gflop %.3f ms %.4f\n", i, m->prof_tag[i].cin, m->prof_tag[i].cout,
+                    m->prof_tag[i].S, m->prof_tag[i].N, m->prof_tag[i].nominal * 1e-9, ms);
   }
+  if (lf) fclose(lf);
+  m->prof_tag.clear();
   out->launches = m->prof_used;
   out->nominal_flops = m->prof_nominal;
   // Z == 2: the z-skip form issues 18 of 27 taps; Z == 1: the centre slice only (9); Z >= 3: all 27 (zero planes staged)
@@ -782,6 +791,7 @@ static void run_conv(Ctx& cx, const TV& x, const ConvW& w, TV y, const TV* res, 
     m->prof_used++;
     const double vox = (double)x.N * x.Z * x.H * x.W;
     m->prof_nominal += 2.0 * (cin_real ? cin_real : x.C) * w.Cout * 27.0 * vox;
+    m->prof_tag.push_back({cin_real ? cin_real : x.C, w.Cout, x.H, x.N, 2.0 * (cin_real ? cin_real : x.C) * w.Cout * 27.0 * vox});
     m->prof_bytes += 4.0 * (vox * x.Cb * 8 + (double)w.ntile * w.Cbi * 27 * 512 + vox * y.Cb * 8);
   }
 }
@@ -816,6 +826,7 @@ static void run_conv_h(Ctx& cx, const TVH& x, const uint16_t* w, const ConvW& cw
     m->prof_used++;
     const double vox = (double)x.N * x.Z * x.H * x.W;
     m->prof_nominal += 2.0 * cin_real * cw.Cout * 27.0 * vox;
+    m->prof_tag.push_back({cin_real, cw.Cout, x.H, x.N, 2.0 * cin_real * cw.Cout * 27.0 * vox});
     m->prof_bytes += 2.0 * vox * x.Cb * 8 + 2.0 * (double)conv_bf16_pack_elems(cw.Cout, cw.Cbi) +
                      ((y16 || fuse_a2) ? 2.0 : 4.0) * vox * y.Cb * 8 + (res16 ? 2.0 * vox * y.Cb * 8 : 0.0);
   }
