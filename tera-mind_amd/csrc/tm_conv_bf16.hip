@@ -173,6 +173,23 @@ template <bool GATE>
 __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&acc)[2][4], int cob0, int h,
                                                   const int (&on)[4], const int (&ooff)[4]) {
   typedef h16_t h16x8 __attribute__((ext_vector_type(8)));
+  // Without a gate (the 3x3x3 conv: the fragment registers of the K loop are dead here) ALL sixteen residual entries of the
+  // wave tile are requested before the first one is used: the epilogue of the 64-cout level-0 layers moves 2 GB per launch
+  // and is otherwise four load -> use -> store rounds, each exposing a full HBM round trip.
+  h16x8 rall[GATE ? 1 : 4][4];
+  if (!GATE && a.res_h) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int cob = cob0 + (g4 >> 1) * 4 + 2 * (g4 & 1) + h;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const bool okk = cob < a.Cob && ooff[mt] >= 0;
+        const long rpl = !okk ? 0 : (!a.res_ls ? (long)cob * a.y_plane + ooff[mt]
+                                               : (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.res_ls));
+        rall[GATE ? 0 : g4][mt] = *(const h16x8*)(a.res_h + (okk ? (long)on[mt] * a.res_h_nstride : 0) + rpl);
+      }
+    }
+  }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
@@ -188,7 +205,8 @@ __device__ __forceinline__ void conv_epilogue_h16(const ConvArgs& a, f32x16 (&ac
       for (int mt = 0; mt < 4; ++mt) {
         ok[mt] = cob < a.Cob && ooff[mt] >= 0;
         pl[mt] = ok[mt] ? (long)cob * a.y_plane + ooff[mt] : 0;
-        if (a.res_h) {
+        if (!GATE && a.res_h) rb[mt] = rall[GATE ? 0 : ct * 2 + q][mt];
+        else if (a.res_h) {
           const long rpl = !a.res_ls ? pl[mt] : (ok[mt] ? (long)cob * (a.y_plane >> 2) + half_res_off(ooff[mt], a.res_ls) : 0);
           rb[mt] = *(const h16x8*)(a.res_h + (ok[mt] ? (long)on[mt] * a.res_h_nstride : 0) + rpl);
         }
