@@ -178,3 +178,20 @@ def test_sample_rejects_unclamped_sampling():
     smp = SpacedDiffusionBeatGans(15, "ddim")
     with pytest.raises(NotImplementedError):
         smp.sample(model=None, shape=(1, 4, 64, 64), noise=torch.zeros(1, 4, 64, 64), clip_denoised=False)
+
+
+def test_consistent_gene_provider_tiles_agree_where_they_overlap():
+    """brain.consistent_gene_provider (the synthetic stand-in for gene tiles cut with overlap from one gene map,
+    utils/MBADataset_tst.py:65-91; precondition of TileSweep(share_halo=True)): a tile's 2-cell halo equals its neighbours'
+    interior rim, in both directions and across the corner; the z-padding slices are zero."""
+    import torch
+    from teramind_amd.brain import Z_PAD, consistent_gene_provider
+    from teramind_amd.config import PathConfig
+    cfg = PathConfig()
+    g = consistent_gene_provider(cfg, "cpu", total_slc=4, density=0.05)
+    a, r, d, dr = g(7, 9), g(7, 10), g(8, 9), g(8, 10)
+    assert a.shape == (20, 20, (4 + 2 * Z_PAD[cfg.rna_slc]) * 500) and float(a.sum()) > 0
+    assert torch.equal(a[:, 16:20], r[:, 0:4]) and torch.equal(a[16:20, :], d[0:4, :]) and torch.equal(a[16:20, 16:20], dr[0:4, 0:4])
+    zp = Z_PAD[cfg.rna_slc] * 500
+    assert float(a[..., :zp].abs().sum()) == 0 and float(a[..., a.shape[-1] - zp:].abs().sum()) == 0
+    assert torch.equal(g(7, 9), a)                      # a pure function of the tile position
