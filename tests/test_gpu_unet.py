@@ -234,6 +234,26 @@ def test_precomputed_rna_pyramid_is_bit_identical(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_cached_rna_level0_is_bit_identical(dtype):
+    """tm_rna_level0 + tm_unet_forward_level0 (gene attention -> down_z -> Upsample kept per tile across the steps of a sweep,
+    TileSweep(cache_level0=True)) return the bits of tm_unet_forward; a level 0 of another (b, p1, p2) is refused."""
+    cfg = PathConfig(compute_dtype=dtype)
+    m = hip_model() if dtype == "f32" else BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    b, P = 2, 2
+    x, t, rna = make_inputs(b, P, seed=13)
+    shp = torch.zeros(b, 4, 64 * P, 64 * P)
+    l0 = m.precompute_rna_level0(rna.to(DEV), b, imgs=shp, patch_size=64)
+    nbytes = b * (P + 1) ** 2 * 29 * 2 * 8 * 8 * 8 * (4 if dtype == "f32" else 2)        # [Ne][29 blocks of 8][Z 2][8][8][8]
+    assert l0.buf.numel() == nbytes
+    for tt in (t, torch.tensor([7, 950])):
+        ref = m(x=x.to(DEV), t=tt.to(DEV), rna=rna.to(DEV), imgs=shp, patch_size=64, want_pred2=True)
+        got = m(x=x.to(DEV), t=tt.to(DEV), rna=l0, imgs=shp, patch_size=64, want_pred2=True)
+        assert torch.equal(got.pred, ref.pred) and torch.equal(got.pred2, ref.pred2)
+    with pytest.raises(ValueError):
+        m(x=x[:9].to(DEV), t=t[:1].to(DEV), rna=l0, imgs=torch.zeros(1, 4, 128, 128), patch_size=64)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_half_resolution_conditioning_is_bit_identical(dtype, tmp_path):
     """The AttnBlock computes SiLU(cond), the 7C adaLN modulation, the cross-cond chunk, k and v once per aligned
     2 x 2 voxel block (cond is a nearest-x2 upsampled RNA level: unet_ours.py:290-295, MBAblocks.py:463-466,472-479,487) and
