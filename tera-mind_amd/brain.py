@@ -425,11 +425,14 @@ def device_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density: flo
     return provider
 
 
-def consistent_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density: float = 0.02):
+def consistent_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density: float = 0.02, max_blocks: int = 0,
+                             max_tiles: int = 0):
     """Synthetic gene tiles that AGREE where neighbouring tiles overlap, like tiles cut with overlap from one gene map
     (utils/MBADataset_tst.py:65-91): the map is a pure function of the absolute 16 x 16-cell block (seeded per block), a
     tile's [20, 20, G] grid is assembled from its own block and the 2-cell rims of its eight neighbours.  Kept on the
-    device; the precondition of TileSweep(share_halo=True)."""
+    device; the precondition of TileSweep(share_halo=True).  max_blocks / max_tiles (> 0): bound the two caches to that many
+    entries (oldest evicted first; a block is 25.6 MB, a dense tile 41.6 MB) -- for sweeps as wide as the whole brain, where
+    the default five-row band of blocks alone would take 53 GB."""
     blocks, cache = {}, {}
     zpad = Z_PAD[cfg.rna_slc] * tiles.GENES
     blk = cfg.patch_size // cfg.gn_sz
@@ -443,6 +446,8 @@ def consistent_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density:
             blocks[(R, C)] = torch.where(u < density, torch.floor(u * (3.0 / density)) + 1.0, torch.zeros_like(u))
             for k in [k for k in blocks if abs(k[0] - R) > 2]:      # the sweep moves along the rows: keep a five-row band
                 del blocks[k]
+            while max_blocks > 0 and len(blocks) > max_blocks:
+                del blocks[next(iter(blocks))]                      # insertion order: the oldest first
         return blocks[(R, C)]
 
     def provider(row, col):
@@ -456,6 +461,8 @@ def consistent_gene_provider(cfg: PathConfig, dev, total_slc: int = 50, density:
             for k in [k for k in cache if k[0] != row]:             # one tile row of dense grids (41.6 MB each) at a time
                 del cache[k]
             cache[(row, col)] = core
+            while max_tiles > 0 and len(cache) > max_tiles:
+                del cache[next(iter(cache))]
         return cache[(row, col)]
     return provider
 
