@@ -243,6 +243,13 @@ int tm_op_conv27_bf16(const void* x_cb8, const void* w_host, const void* bias_ho
                       int N, int Cin, int Cout, int S, int dtype, int waves, const void* res_h16, void* y_h16,
                       int ups, int res_half, void* stream);
 
+/* Timing hook: `iters` launches of that conv in the forms the model uses (16-bit stream output, optional 16-bit
+ * residual, fused norm epilogue, upsampled-input form) on random device data in [-1, 1); *ms_per_launch = mean launch
+ * duration between two events after one warm-up launch.  waves: 0 | 4 | 8 as above, 9 = the lockstep 8-wave kernel
+ * (kept for A/B against the ping-pong form that `8` selects). */
+int tm_op_conv27_time(int N, int Cin, int Cout, int S, int dtype, int waves, int ups, int with_res, int fused,
+                      int iters, float* ms_per_launch, void* stream);
+
 /* The same conv with the ResBlock mid-section fused into its epilogue (Cout in {64, 128}): out_layers[0]
  * RMSNorm(C) * norm_w -> x * (1 + scale) + shift -> SiLU (model/MBAblocks.py:196-203,356-367), written as the 16-bit CB8
  * tensor a2_out [N][Cout/8][2][S][S][8] (the second conv's input).  norm_w [Cout], scale / shift [ceil(N/per_image)][Cout]

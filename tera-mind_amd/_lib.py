@@ -70,6 +70,7 @@ SIGNATURES = {
     "tm_op_conv_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "tm_op_conv27_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "tm_op_conv27_fused": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    "tm_op_conv27_time": (c_int, [c_int] * 10 + [c_void_p, c_void_p]),
     "tm_op_conv1_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4),
     "tm_op_conv1_concat": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "tm_op_prep_h16": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_int, c_int, c_void_p, c_void_p, C.c_long] +

@@ -26,6 +26,7 @@
 #define TM_H16_T _Float16
 #define TM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define conv27_bf16 conv27_f16
+#define conv27_pp conv27_pp_f16
 #define conv1_bf16 conv1_f16
 #define window_attn_bf16 window_attn_f16
 #define window_attn_long window_attn_long_f16
@@ -323,13 +324,17 @@ __device__ __forceinline__ void col_to_vox(int T, int i32, int& ps, int& r, int&
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// the same piece as `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`: M0 = LDS base, per-lane byte offset + scalar byte offset
+#define TM_BLDS16(rsrc, voff, soff, lptr)                                                      \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
+
 #ifndef TM_ABL
 #define TM_ABL 0      // diagnostic builds: 1 = no stage barrier, 8 = barrier without waiting for the LDS-DMAs, 2 = no fragment ds_reads after a stage's first tap, 4 = no LDS-DMA after stage 0
 #endif
 #ifdef TM_STAMPS
 // Diagnostic build only (make diag -> libteramind_hip_diag.so, tools/conv27_stamps.py): wave 0 of every workgroup records
 // s_memtime at kernel entry, main-loop entry, main-loop exit and kernel exit into a buffer of its own.
-__device__ unsigned long long* g_tm_stamps = nullptr;      // [capacity][8]: t0 t1 t2 t3 grid bid tag realtime
+__device__ unsigned long long* g_tm_stamps = nullptr;      // [capacity][16]: t0 t1 t2 t3 grid bid tag realtime + 8 kernel-specific words
 __device__ unsigned int g_tm_stamp_cap = 0;
 __device__ unsigned int g_tm_stamp_next = 0;
 #define TM_STAMP(i) do { if (stamp_slot) stamp_slot[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   if (threadIdx.x == 0 && g_tm_stamps) {
     const unsigned int k = atomicAdd(&g_tm_stamp_next, 1u);
     if (k < g_tm_stamp_cap) {
-      stamp_slot = g_tm_stamps + (size_t)k * 8;
+      stamp_slot = g_tm_stamps + (size_t)k * 16;
       stamp_slot[4] = gridDim.x; stamp_slot[5] = blockIdx.x;
       stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + (unsigned long long)(TN * 1000 + TW * 10 + (FUSE ? 1 : 0) + (UPS ? 2 : 0));
       stamp_slot[7] = __builtin_amdgcn_s_memrealtime();
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
   const int i32 = lane & 31, h = lane >> 5;
   const int wn = wv % G::WNW, wm = wv / G::WNW;
 
@@ -383,11 +389,17 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   // ---- staging descriptors: piece i = tid + k*NT lands in LDS slot WPIECES + i (lane-linear per wave,
   //      as the LDS-DMA requires); halo slots outside the plane / patch are never loaded and keep the
   //      zeros written once below ----
-  long xoff[G::PX];
+  // Pieces are issued as `buffer_load_dwordx4 ... offen lds`: a per-lane 32-bit byte offset that never changes (xvo[], wvo)
+  // plus a scalar offset per stage, against two descriptors built once -- the packed weights of this n-tile (phase), and the
+  // activations of this workgroup's patch group.  A piece then costs two scalar adds (M0, the scalar offset) and the load
+  // itself instead of ~25 instructions of 64-bit address arithmetic per piece (200 per wave per stage, issued between the
+  // MFMAs).  Lanes whose halo slot lies outside the plane / patch carry an offset past the descriptor's range: the
+  // hardware drops them (the slot keeps / gets the zeros of the padding).
+  unsigned xvo[G::PX];
 #pragma unroll
   for (int k = 0; k < G::PX; ++k) {
     const int i = tid + k * NT;
-    long off = -1;
+    unsigned off = 0x80000000u;                       // past any descriptor range, and no 32-bit wrap when the scalar offset is added
     if (i < G::XPIECES) {
       const int pl = i / (2 * G::XSP);                 // plane of the stage (UPS: both input planes; otherwise 0)
       const int half = (i - pl * 2 * G::XSP) / G::XSP;
@@ -399,14 +411,18 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
         const int n = pg * G::NPB + ps;
         const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
         if (hc < G::HC && n < a.N && y >= 0 && y < S && x >= 0 && x < S)
-          off = (long)n * ah.x_nstride_e + (long)half * ah.x_plane_e + (long)pl * S * S * 8 + ((long)y * S + x) * 8;
+          off = (unsigned)(((long)ps * ah.x_nstride_e + (long)half * ah.x_plane_e + (long)pl * S * S * 8 + ((long)y * S + x) * 8) * 2);
       }
     }
-    xoff[k] = off;
+    xvo[k] = off;
   }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(xg + (long)pg * G::NPB * ah.x_nstride_e), 0, (int)((long)G::NPB * ah.x_nstride_e * 2), 0x00020000);
   // packed weights: [n-tile][pair][kz 3][9 taps][TN][2][8]; UPS: [phase][n-tile][pair][kz 3][4 taps][TN][2][8]
-  const h16_t* wsrc = UPS ? wg + ((long)(py * 2 + px) * a.ntile + nt) * ah.Cbp * 12 * TN * 16 + (long)tid * 8
-                          : wg + (long)nt * ah.Cbp * 27 * TN * 16 + (long)tid * 8;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(UPS ? wg + ((long)(py * 2 + px) * a.ntile + nt) * ah.Cbp * 12 * TN * 16 : wg + (long)nt * ah.Cbp * 27 * TN * 16), 0,
+      ah.Cbp * (UPS ? 12 : 27) * TN * 32, 0x00020000);
+  const int wvo = tid * 16;
 
   // ---- fragment addresses (16-byte units inside a buffer) ----
   int xb[4], on[4], ooff[4];
@@ -454,12 +470,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
     if (p < G::PW) {
       const int k = p;
       // UPS (Z == 2): the stage's planes 0, 1 meet kz = 1 - zo, 2 - zo: eight consecutive taps of the phase's 12
-      const h16_t* wp = UPS ? wsrc + ((long)cbp * 3 + (1 - zo)) * 4 * TN * 16 : wsrc + ((long)cbp * 3 + (zi + 1 - zo)) * 9 * TN * 16;
-      if (G::WPIECES % NT == 0 || k * NT + wv * 64 < G::WPIECES) TM_GLDS16(wp + (long)k * NT * 8, base + k * NT + wv * 64);
+      const int ws = UPS ? (cbp * 3 + (1 - zo)) * 4 * TN * 32 : (cbp * 3 + (zi + 1 - zo)) * 9 * TN * 32;
+      if (G::WPIECES % NT == 0 || k * NT + wvu * 64 < G::WPIECES) TM_BLDS16(wrs, wvo, ws + k * NT * 16, base + k * NT + wvu * 64);
     } else {
       const int k = p - G::PW;
-      const h16_t* xp = xg + (long)cbp * 2 * ah.x_plane_e + (UPS ? 0 : (long)zi * S * S * 8);
-      if (xoff[k] >= 0) TM_GLDS16(xp + xoff[k], base + G::WPIECES + k * NT + wv * 64);
+      const int xs = (cbp * 2 * (int)ah.x_plane_e + (UPS ? 0 : zi * S * S * 8)) * 2;
+      if (G::XPIECES % NT == 0 || k * NT + wvu * 64 < G::XPIECES) TM_BLDS16(xrs, xvo[k], xs, base + G::WPIECES + k * NT + wvu * 64);
     }
   };
   constexpr int NP = G::PW + G::PX;                    // DMA instructions per wave per stage
@@ -563,6 +579,337 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   TM_STAMP(3);
 #endif
 }
+// ---- the 8-wave form as a PING-PONG of its two wave groups ------------------------------------------------------------
+// Same tiles, LDS images, operand maps and epilogues as conv27_bf16<.., 8, ..>; what changes is WHEN a wave does what.
+// Waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the four SIMDs.  In the loop above both partners of a SIMD ran the
+// same stream in lockstep: their ds_reads, their LDS-DMA issue (100-200 cycles of blocked issue each) and their MFMAs
+// coincided, and the stage barrier made every wave pay for the slowest (75 % of the MFMA-ideal cycles; 96 % without the
+// barrier, 95 % without the DMAs: profiles/r02_conv27_mainloop_ablation.txt).  Here the K loop is cut into SEGMENTS of
+// SEGT taps (3 of a stage's 9; 2 of 8 in the upsampled-input form) and the groups alternate strictly, one barrier apart
+// (the stagger barrier group 1 executes once): while one group issues the 8 * SEGT MFMAs of a segment back to back at
+// raised priority, the other requests the fragments of ITS next segment (ds_read_b128 into the one fragment set a wave now
+// needs) and issues its share of the next stage's LDS-DMAs; at the next barrier the roles swap.  A SIMD's matrix pipe is
+// handed from one partner to the other with nothing but MFMAs in the handed-over stream, and every memory instruction of
+// a wave is issued under its partner's MFMAs (cdna guide: the 8-phase template's two wave groups).
+//
+// Interval k (between workgroup barriers k and k+1): k = 2s: group 0 computes segment s, group 1 loads segment s;
+// k = 2s + 1: group 0 loads segment s + 1, group 1 computes segment s.  LDS protocol (two stage buffers as before):
+//   * a wave waits for its own ds_reads (lgkmcnt(0)) BEFORE the barrier that ends its load interval, so stage L - 1's
+//     buffer is dead once both groups have passed the barrier behind their load of (L - 1, last segment), which is before
+//     group 0's load of (L, segment 0): every load step of stage L may refill that buffer with pieces of stage L + 1;
+//   * LDS-DMA is a throughput resource of its own -- a CU takes in 20-30 B/clk of it, and the 56 KB a stage needs are half
+//     of a stage's MFMA time at that rate -- so the pieces are dealt EVENLY over the load steps (PPSched below), a few per
+//     step, issued between the fragment reads of the step's taps (a wave that issues pieces back to back sits blocked at
+//     the second for as long as the first takes, ~200 cycles by the stamps, with its ds_reads queued behind);
+//   * ROLLING DRAIN: a wave begins every load step with vmcnt(0) -- that retires the pieces of its previous load step, two
+//     intervals old and long landed -- so a piece issued in interval k is complete and, behind the barrier that ends
+//     interval k + 2, visible to everyone from interval k + 3 on.  A piece first read in segment a of stage L + 1 (group
+//     0's load of it is interval 2 ((L + 1) NSEG + a) - 1) may therefore be issued in the load step of (L, j) -- group 1's
+//     is interval 2 (L NSEG + j) -- for j <= NSEG - 2 + a: the halo tile and the first segment's weights go into the first
+//     NSEG - 1 steps, later segments' weights anywhere.
+// Both groups execute the same number of barriers (group 1: the stagger barrier instead of the one behind its last MFMAs).
+template <int TN, int TW, bool UPS>
+struct PPSched {
+  using G = HGeo<TN, TW, 8, UPS>;
+  static constexpr int SEGT = UPS ? 2 : 3;             // taps per segment
+  static constexpr int NSEG = G::NTAPS / SEGT;         // segments (= load steps) per stage
+  static constexpr int NP = G::PW + G::PX;             // LDS-DMA pieces (wave-instructions) per wave per stage
+  // first segment that reads piece p: weight piece k holds slots [k NT, (k + 1) NT) of [tap][TN][2]; a halo piece is read
+  // from the first tap on (UPS: the pieces wholly inside plane 1 from tap 4 on)
+  __host__ __device__ static constexpr int first_seg(int p) {
+    if (p < G::PW) return (p * G::NT) / (TN * 2) / SEGT;
+    return (UPS && (p - G::PW) * G::NT >= 2 * G::XSP) ? 4 / SEGT : 0;
+  }
+  __host__ __device__ static constexpr int deadline(int p) {
+    const int d = NSEG - 2 + first_seg(p);
+    return d < NSEG - 1 ? d : NSEG - 1;
+  }
+  // Greedy deal: pieces in order of deadline (halo pieces before weight pieces, then by index), each to the least loaded
+  // step it may go to (ties: the earliest).
+  __host__ __device__ static constexpr int step_of(int p) {
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dl = 0; dl < NSEG; ++dl)
+      for (int pass = 0; pass < 2; ++pass)
+        for (int q = 0; q < NP; ++q) {
+          if (deadline(q) != dl || ((q >= G::PW) != (pass == 0))) continue;
+          int best = 0;
+          for (int st = 1; st <= dl; ++st)
+            if (cnt[st] < cnt[best]) best = st;
+          if (q == p) return best;
+          ++cnt[best];
+        }
+    return 0;
+  }
+  // piece[step][n]: the n-th piece (in index order) of a load step, cnt[step] of them
+  struct Tbl { int piece[4][16]; int cnt[4]; };
+  __host__ __device__ static constexpr Tbl make() {
+    Tbl t = {};
+    for (int st = 0; st < 4; ++st) {
+      t.cnt[st] = 0;
+      for (int n = 0; n < 16; ++n) t.piece[st][n] = -1;
+    }
+    for (int q = 0; q < NP; ++q) {
+      const int st = step_of(q);
+      t.piece[st][t.cnt[st]++] = q;
+    }
+    return t;
+  }
+};
+template <int TN, int TW, bool FUSE, bool UPS = false>
+__global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
+  using G = HGeo<TN, TW, 8, UPS>;
+  constexpr int NTAPS = G::NTAPS;
+  constexpr int NT = G::NT;
+  constexpr int SEGT = UPS ? 2 : 3;                    // taps per segment
+  constexpr int NSEG = NTAPS / SEGT;                   // segments per stage
+  static_assert(NSEG * SEGT == NTAPS && NSEG >= 2, "segment shape");
+  const ConvArgs& a = ah.c;
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+#ifdef TM_STAMPS
+  // diagnostic build: lane 0 of wave 0 (group 0) and of wave 4 (group 1) each own a 16-word slot: [0..3] entry / loop entry /
+  // loop exit / exit, [4] grid [5] block [6] tag (+4: group 1) [7] realtime, [8..12] cycles summed over the segments:
+  // MFMA issue | wait at the barrier behind it | LDS-DMA issue | ds_reads until landed | wait at the barrier before the MFMAs
+  unsigned long long* stamp_slot = nullptr;
+  if ((threadIdx.x & 255) == 0 && g_tm_stamps) {
+    const unsigned int k = atomicAdd(&g_tm_stamp_next, 1u);
+    if (k < g_tm_stamp_cap) {
+      stamp_slot = g_tm_stamps + (size_t)k * 16;
+      stamp_slot[4] = gridDim.x; stamp_slot[5] = blockIdx.x;
+      stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + (unsigned long long)(TN * 1000 + TW * 10 + (FUSE ? 1 : 0) + (UPS ? 2 : 0) + (threadIdx.x ? 4 : 0));
+      stamp_slot[7] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  unsigned long long pp_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, pp_prev = 0ull;
+#define PP_STAMP(i_)                                                                                       \
+  do {                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    unsigned long long t_;                                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+    pp_acc[i_] += t_ - pp_prev; pp_prev = t_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+  } while (0)
+  TM_STAMP(0);
+#else
+#define PP_STAMP(i_) do { } while (0)
+#endif
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);  // provably wave-uniform: LDS-DMA bases and role branches stay scalar
+  const int grp = wvu >> 2;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int wn = wv % G::WNW, wm = wv / G::WNW;
+
+  const int S = a.S;
+  const int tiles_c = S / TW, tiles_r = S / G::TR;
+  const int tiles = tiles_c * tiles_r;
+  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int nt = bid % a.ntile;
+  int mt_ = bid / a.ntile;
+  int py = 0, px = 0;
+  if (UPS) { py = (mt_ >> 1) & 1; px = mt_ & 1; mt_ >>= 2; }
+  const int pg = mt_ / (a.Z * tiles);
+  mt_ -= pg * a.Z * tiles;
+  const int zo = mt_ / tiles;
+  mt_ -= zo * tiles;
+  const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
+
+  const h16_t* xg = (const h16_t*)a.x;
+  const h16_t* wg = (const h16_t*)a.w;
+
+  // staging descriptors, fragment addresses, output coordinates: exactly those of conv27_bf16
+  // staging descriptors as in conv27_bf16: buffer_load ... lds pieces, per-lane offsets fixed, scalar offset per stage
+  unsigned xvo[G::PX];
+#pragma unroll
+  for (int k = 0; k < G::PX; ++k) {
+    const int i = tid + k * NT;
+    unsigned off = 0x80000000u;                       // past any descriptor range, and no 32-bit wrap when the scalar offset is added
+    if (i < G::XPIECES) {
+      const int pl = i / (2 * G::XSP);                 // plane of the stage (UPS: both input planes; otherwise 0)
+      const int half = (i - pl * 2 * G::XSP) / G::XSP;
+      int v = i - (pl * 2 + half) * G::XSP;
+      if (v < G::XS) {
+        const int hc = v % G::HCP; v /= G::HCP;
+        const int hr = v % G::HR;
+        const int ps = v / G::HR;
+        const int n = pg * G::NPB + ps;
+        const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
+        if (hc < G::HC && n < a.N && y >= 0 && y < S && x >= 0 && x < S)
+          off = (unsigned)(((long)ps * ah.x_nstride_e + (long)half * ah.x_plane_e + (long)pl * S * S * 8 + ((long)y * S + x) * 8) * 2);
+      }
+    }
+    xvo[k] = off;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(xg + (long)pg * G::NPB * ah.x_nstride_e), 0, (int)((long)G::NPB * ah.x_nstride_e * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(UPS ? wg + ((long)(py * 2 + px) * a.ntile + nt) * ah.Cbp * 12 * TN * 16 : wg + (long)nt * ah.Cbp * 27 * TN * 16), 0,
+      ah.Cbp * (UPS ? 12 : 27) * TN * 32, 0x00020000);
+  const int wvo = tid * 16;
+  int xb[4], on[4], ooff[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int ps, r, c;
+    col_to_vox<TW, G::TR>(wm * 4 + mt, i32, ps, r, c);
+    xb[mt] = G::WPIECES + h * G::XSP + (ps * G::HR + r) * G::HCP + c;
+    const int n = pg * G::NPB + ps;
+    on[mt] = n;
+    const int y = tr * G::TR + r, x = tc * TW + c;
+    if (UPS) ooff[mt] = (n < a.N) ? ((zo * 2 * S + 2 * y + py) * 2 * S + 2 * x + px) * 8 : -1;
+    else ooff[mt] = (n < a.N) ? ((zo * S + y) * S + x) * 8 : -1;
+  }
+  const int wb = (wn * 64 + i32) * 2 + (h ^ ((i32 >> 3) & 1));
+  auto tap_xd = [&](int t) __attribute__((always_inline)) {
+    return UPS ? (t >> 2) * 2 * G::XSP + (((t >> 1) & 1) + py) * G::HCP + (t & 1) + px : (t / 3) * G::HCP + (t % 3);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
+
+  for (int i = tid; i < G::XPIECES; i += NT) {
+    lds16[G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
+    lds16[G::BUF16 + G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+
+  const int zi0 = UPS ? 0 : (zo > 0 ? zo - 1 : 0);
+  const int npl = UPS ? 1 : (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;      // stages per channel-block pair
+  const int NH = npl * ah.Cbp;
+  // LDS-DMA piece p of the stage (cbp, zi) into the buffer at `base`: the weight pieces first, then the halo-tile pieces
+  auto issue_piece = [&](u32x4* base, int cbp, int zi, int p) __attribute__((always_inline)) {
+    if (p < G::PW) {
+      const int k = p;
+      const int ws = UPS ? (cbp * 3 + (1 - zo)) * 4 * TN * 32 : (cbp * 3 + (zi + 1 - zo)) * 9 * TN * 32;
+      if (G::WPIECES % NT == 0 || k * NT + wvu * 64 < G::WPIECES) TM_BLDS16(wrs, wvo, ws + k * NT * 16, base + k * NT + wvu * 64);
+    } else {
+      const int k = p - G::PW;
+      const int xs = (cbp * 2 * (int)ah.x_plane_e + (UPS ? 0 : zi * S * S * 8)) * 2;
+      if (G::XPIECES % NT == 0 || k * NT + wvu * 64 < G::XPIECES) TM_BLDS16(xrs, xvo[k], xs, base + G::WPIECES + k * NT + wvu * 64);
+    }
+  };
+  using SCH = PPSched<TN, TW, UPS>;
+  constexpr int NP = SCH::NP;                          // DMA instructions per wave per stage
+  constexpr typename SCH::Tbl sch = SCH::make();       // which pieces go with which load step
+  static_assert(NP <= 16 && NSEG <= 4, "schedule table shape");
+
+  // prologue: stages 0 and 1 into the two buffers, all of it landed before the first read
+#pragma unroll
+  for (int p = 0; p < NP; ++p) issue_piece(lds16, 0, zi0, p);
+  if (NH > 1) {
+    const int c1 = 1 / npl, z1 = zi0 + 1 % npl;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) issue_piece(lds16 + G::BUF16, c1, z1, p);
+  }
+  __syncthreads();                                     // vmcnt(0) + barrier
+  TM_STAMP(1);
+#ifdef TM_STAMPS
+  pp_prev = __builtin_amdgcn_s_memtime();
+#endif
+
+  bf16x8 wf[SEGT][2], xf[SEGT][4];
+  auto loadseg = [&](const u32x4* b, int j) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < SEGT; ++t) {
+      const int tap = j * SEGT + t;
+      const int xd = tap_xd(tap);
+      wf[t][0] = __builtin_bit_cast(bf16x8, b[tap * TN * 2 + wb]);
+      wf[t][1] = __builtin_bit_cast(bf16x8, b[tap * TN * 2 + 64 + wb]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xf[t][mt] = __builtin_bit_cast(bf16x8, b[xb[mt] + xd]);
+    }
+  };
+  // coordinates of the stage whose pieces are being issued: the stage after the one whose segments are being loaded
+  int f_cbp = (NH > 1) ? 1 / npl : 0, f_zi = zi0 + ((NH > 1) ? 1 % npl : 0);
+  // load step of segment j: (dma) retire this wave's older pieces, then the segment's ds_reads from `rb` tap by tap with this
+  // step's pieces of stage (f_cbp, f_zi) between them, into `db`
+  auto load_step = [&](const u32x4* rb, int j, bool dma, u32x4* db) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < SEGT; ++t) {
+      if (t < sch.cnt[j]) {
+        if (dma) issue_piece(db, f_cbp, f_zi, sch.piece[j][t]);
+      }
+      const int tap = j * SEGT + t;
+      const int xd = tap_xd(tap);
+      wf[t][0] = __builtin_bit_cast(bf16x8, rb[tap * TN * 2 + wb]);
+      wf[t][1] = __builtin_bit_cast(bf16x8, rb[tap * TN * 2 + 64 + wb]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xf[t][mt] = __builtin_bit_cast(bf16x8, rb[xb[mt] + xd]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (dma) {
+#pragma unroll
+      for (int n = SEGT; n < 16; ++n)
+        if (n < sch.cnt[j]) issue_piece(db, f_cbp, f_zi, sch.piece[j][n]);
+    }
+  };
+  loadseg(lds16, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) only
+      asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one interval behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int hs = 0; hs < NH; ++hs) {
+    const bool more = hs + 1 < NH;
+    const bool fetch_cur = hs >= 1 && more;            // load steps 1 .. of stage hs carry pieces of stage hs + 1 (stage 1: the prologue's)
+    const bool fetch_next = hs + 2 < NH;               // load step 0 of stage hs + 1 (end of this iteration): pieces of stage hs + 2
+    u32x4* buf = lds16 + (hs & 1) * G::BUF16;
+    u32x4* nbuf = lds16 + ((hs + 1) & 1) * G::BUF16;
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j) {
+      // ---- compute interval of segment (hs, j): fragments are in registers (waited for before the barrier) ----
+      __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) only
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(4);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < SEGT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[ct][mt] = TM_MFMA16(wf[t][ct], xf[t][mt], acc[ct][mt]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(0);
+      if (!(j == NSEG - 1 && !more && grp == 1)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(1);
+      // ---- load interval: the next segment's fragments + this step's pieces of the stage after the one being loaded ----
+      if (j < NSEG - 1) {
+        load_step(buf, j + 1, fetch_cur, nbuf);
+      } else if (more) {
+        if (++f_zi == zi0 + npl) { f_zi = zi0; ++f_cbp; }       // (f_cbp, f_zi) = stage hs + 2
+        load_step(nbuf, 0, fetch_next, buf);
+      }
+#ifdef TM_STAMPS
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      PP_STAMP(3);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  TM_STAMP(2);
+#ifdef TM_STAMPS
+  if (stamp_slot) { for (int i = 0; i < 5; ++i) stamp_slot[8 + i] = pp_acc[i]; }
+#endif
+  if (FUSE) fused_norm_epilogue<G::WNW>(ah, acc, wn, wm, i32, h, on, ooff, (float*)lds16);
+  else conv_epilogue_h16<false>(a, acc, (nt * G::WNW + wn) * 8, h, on, ooff);
+#ifdef TM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TM_STAMP(3);
+#endif
+#undef PP_STAMP
+}
+
 #ifdef TM_STAMPS
 #ifndef TM_H16_F16
 extern "C" int tm_diag_stamps(unsigned long long* dev_buf, unsigned int capacity) {     // dev_buf == null: disable
@@ -616,7 +963,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   if (threadIdx.x == 0 && g_tm_stamps) {
     const unsigned int k = atomicAdd(&g_tm_stamp_next, 1u);
     if (k < g_tm_stamp_cap) {
-      stamp_slot = g_tm_stamps + (size_t)k * 8;
+      stamp_slot = g_tm_stamps + (size_t)k * 16;
       stamp_slot[4] = gridDim.x; stamp_slot[5] = blockIdx.x;
       stamp_slot[6] = (unsigned long long)ah.Cbp * 1000000ull + 500000ull + (unsigned long long)(TN * 1000 + NWV * 10 + (MS ? 1 : 0));
       stamp_slot[7] = __builtin_amdgcn_s_memrealtime();
@@ -1493,6 +1840,9 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     if (!L.res_h || (1 << ls) != L.y.H || L.y.H != L.y.W || ls < 1) return hipErrorInvalidValue;
     a.res_ls = ls;
   }
+  // TM_CONV27_PP=0 (environment, read once) or force_waves == 9: the lockstep 8-wave kernel instead of the ping-pong one (A/B)
+  static const int env_pp = [] { const char* e = getenv("TM_CONV27_PP"); return e ? atoi(e) : 1; }();
+  const bool use_pp = env_pp != 0 && L.force_waves != 9;
   if (L.ups) {
     // upsampled-input form: TN = 128 only (the up blocks of the model family have Cout >= 128), Z == 2, no residual
     if (TN != 128 || L.x.Z != 2 || L.res || L.res_h || (S != 8 && S != 16 && S != 32 && S != 64)) return hipErrorInvalidValue;
@@ -1517,7 +1867,28 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<128, TW_, true, NWV_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
     else hipLaunchKernelGGL((conv27_bf16<128, TW_, false, NWV_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
   } while (0)
-    if (S >= 32) TM_LAUNCHU(32, 8); else if (S == 16) TM_LAUNCHU(16, 8); else TM_LAUNCHU(8, 4);
+#define TM_LAUNCHUPP(TW_)                                                                        \
+  do {                                                                                          \
+    using G = HGeo<128, TW_, 8, true>;                                                          \
+    static DevOnce attr_done;                                                                   \
+    if (attr_done.need()) {                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)conv27_pp<128, TW_, false, true>,         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_pp<128, TW_, true, true>, \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_done.mark();                                                                         \
+    }                                                                                           \
+    const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
+    const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
+    const long grid = pgs * a.Z * tiles * 4 * a.ntile;                                          \
+    if (ah.fuse) hipLaunchKernelGGL((conv27_pp<128, TW_, true, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+    else hipLaunchKernelGGL((conv27_pp<128, TW_, false, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+  } while (0)
+    if (S >= 32) { if (use_pp) TM_LAUNCHUPP(32); else TM_LAUNCHU(32, 8); }
+    else if (S == 16) { if (use_pp) TM_LAUNCHUPP(16); else TM_LAUNCHU(16, 8); }
+    else TM_LAUNCHU(8, 4);
+#undef TM_LAUNCHUPP
 #undef TM_LAUNCHU
     return hipGetLastError();
   }
@@ -1525,7 +1896,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res || L.res_h)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
   static const int env27 = env_waves("TM_CONV27_WAVES");
-  const int fw27 = L.force_waves ? L.force_waves : env27;
+  const int fw27 = L.force_waves == 9 ? 8 : (L.force_waves ? L.force_waves : env27);
   if (fw27 != 0 && fw27 != 4 && fw27 != 8) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
   do {                                                                                          \
@@ -1533,7 +1904,25 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     const long tiles8 = (long)(S / TW_) * (S / G8::TR);                                         \
     const long grid8 = ((a.N + G8::NPB - 1) / G8::NPB) * a.Z * tiles8 * a.ntile;                \
     const bool w8 = fw27 ? fw27 == 8 : grid8 >= 256;                                            \
-    if (w8) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4);                            \
+    if (w8 && use_pp) TM_LAUNCHPP(TN_, TW_); else if (w8) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4); \
+  } while (0)
+#define TM_LAUNCHPP(TN_, TW_)                                                                    \
+  do {                                                                                          \
+    using G = HGeo<TN_, TW_, 8>;                                                                \
+    static DevOnce attr_done;                                                                   \
+    if (attr_done.need()) {                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)conv27_pp<TN_, TW_, false>,               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_pp<TN_, TW_, true>,      \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_done.mark();                                                                         \
+    }                                                                                           \
+    const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
+    const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
+    const long grid = pgs * a.Z * tiles * a.ntile;                                              \
+    if (ah.fuse) hipLaunchKernelGGL((conv27_pp<TN_, TW_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+    else hipLaunchKernelGGL((conv27_pp<TN_, TW_, false>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
   } while (0)
 #define TM_LAUNCHHW(TN_, TW_, NWV_)                                                              \
   do {                                                                                          \
@@ -1558,6 +1947,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   } else {
     if (S >= 32) TM_LAUNCHH(128, 32); else if (S == 16) TM_LAUNCHH(128, 16); else TM_LAUNCHH(128, 8);
   }
+#undef TM_LAUNCHPP
 #undef TM_LAUNCHHW
 #undef TM_LAUNCHH
   return hipGetLastError();

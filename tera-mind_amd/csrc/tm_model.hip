@@ -1671,7 +1671,7 @@ static int op_conv27_h16(const void* x_cb8, const void* w_host, const void* bias
                          int per_image, void* a2_out, void* stream, const void* res_h16 = nullptr, void* y_h16 = nullptr,
                          int ups = 0, int res_half = 0) {
   if (!is_h16(dtype)) return fail(TM_ERR_ARG, "dtype must be TM_DTYPE_BF16 or TM_DTYPE_F16");
-  if (waves != 0 && waves != 4 && waves != 8) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4 or 8");
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 9) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4, 8 or 9 (lockstep 8-wave form)");
   const bool f16 = dtype == TM_DTYPE_F16, fused = norm_w_host != nullptr;
   if (fused && (!scale_host || !shift_host || !a2_out || per_image < 1 || (Cout != 64 && Cout != 128)))
     return fail(TM_ERR_ARG, "fused epilogue needs Cout in {64, 128}, scale / shift / a2 and per_image >= 1");
@@ -1745,6 +1745,79 @@ extern "C" int tm_op_conv27_fused(const void* x_cb8, const void* w_host, const v
   // the launcher takes the output geometry from `y`; the fused form never writes it
   return op_conv27_h16(x_cb8, w_host, bias_host, a2_out, N, Cin, Cout, S, dtype, waves, norm_w_host, scale_host, shift_host,
                        per_image, a2_out, stream);
+}
+// Timing hook of the 16-bit 3x3x3 conv on random device data (uniform in [-1, 1): the clock the chip holds depends on the
+// operand bits, cdna guide rule 25): the model's launch forms -- 16-bit stream output with an optional 16-bit residual, the
+// fused norm epilogue, the upsampled-input form -- `iters` launches between two events after one warm-up launch.
+__global__ void fill_h16_kernel(uint16_t* p, size_t n, unsigned seed, int f16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned hsh = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) * 40503u ^ seed;
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13; hsh *= 3266489917u; hsh ^= hsh >> 16;
+    const float v = (float)(hsh >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    uint16_t u;
+    if (f16) { const _Float16 hf = (_Float16)v; u = __builtin_bit_cast(uint16_t, hf); }
+    else { const __bf16 bf = (__bf16)v; u = __builtin_bit_cast(uint16_t, bf); }
+    p[i] = u;
+  }
+}
+extern "C" int tm_op_conv27_time(int N, int Cin, int Cout, int S, int dtype, int waves, int ups, int with_res, int fused,
+                                 int iters, float* ms_per_launch, void* stream) {
+  if (!is_h16(dtype) || iters < 1 || !ms_per_launch || N < 1) return fail(TM_ERR_ARG, "bad argument");
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 9) return fail(TM_ERR_ARG, "waves must be 0 (auto), 4, 8 or 9 (lockstep 8-wave form)");
+  if (fused && (Cout != 64 && Cout != 128)) return fail(TM_ERR_ARG, "fused epilogue needs Cout in {64, 128}");
+  if (ups && (Cout % 128 || with_res)) return fail(TM_ERR_ARG, "upsampled-input form: Cout a multiple of 128, no residual");
+  const bool f16 = dtype == TM_DTYPE_F16;
+  hipStream_t st = (hipStream_t)stream;
+  const int Cbi = (Cin + 7) / 8, Cbe = (Cbi + 1) / 2 * 2, nt64 = (Cout + 63) / 64, So = ups ? 2 * S : S;
+  const size_t nw = ups ? conv_bf16_pack_ups_elems(Cout, Cbi) : conv_bf16_pack_elems(Cout, Cbi);
+  const long vox = (long)2 * S * S, voxo = (long)2 * So * So;
+  const size_t nx = (size_t)N * Cbe * vox * 8, ny = (size_t)N * ((Cout + 7) / 8) * voxo * 8;
+  uint16_t *dw = nullptr, *dx = nullptr, *dy = nullptr, *dr = nullptr;
+  float* df = nullptr;
+  const size_t nf = (size_t)nt64 * 64 + (size_t)Cout * 3;
+  HIP_TRY(hipMalloc((void**)&dw, nw * 2));
+  HIP_TRY(hipMalloc((void**)&dx, nx * 2));
+  HIP_TRY(hipMalloc((void**)&dy, ny * 2));
+  if (with_res) HIP_TRY(hipMalloc((void**)&dr, ny * 2));
+  HIP_TRY(hipMalloc((void**)&df, nf * sizeof(float)));
+  hipLaunchKernelGGL(fill_h16_kernel, dim3(2048), dim3(256), 0, st, dw, nw, 11u, f16 ? 1 : 0);
+  hipLaunchKernelGGL(fill_h16_kernel, dim3(2048), dim3(256), 0, st, dx, nx, 23u, f16 ? 1 : 0);
+  if (with_res) hipLaunchKernelGGL(fill_h16_kernel, dim3(2048), dim3(256), 0, st, dr, ny, 37u, f16 ? 1 : 0);
+  std::vector<float> fp(nf, 0.f);
+  for (size_t i = 0; i < nf; ++i) fp[i] = 0.01f * (float)((int)(i * 37 % 101) - 50);
+  for (int i = 0; i < Cout; ++i) fp[(size_t)nt64 * 64 + i] = 1.0f + 0.001f * (float)(i % 17);      // norm_w
+  HIP_TRY(hipMemcpyAsync(df, fp.data(), nf * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  ConvLaunchH L;
+  L.x.p = dx; L.x.N = N; L.x.Cb = Cbe; L.x.C = Cbe * 8; L.x.Z = 2; L.x.H = S; L.x.W = S; L.x.nstride = (long)Cbe * vox * 8;
+  L.w = dw; L.bias = df; L.Cout = Cout; L.force_waves = waves;
+  L.y = view_cb8(dy, N, Cout, 2, So, So);
+  L.ups = ups;
+  TVH resh = as_h(L.y);
+  if (with_res) { resh.p = dr; L.res_h = &resh; }
+  L.y_h = dy; L.yh_nstride = L.y.nstride;
+  if (fused) {
+    L.fuse_norm = 1; L.norm_w = df + nt64 * 64; L.mod_scale = L.norm_w + Cout; L.mod_shift = L.mod_scale + Cout;
+    L.mod_stride = 0; L.per_image = N;
+    L.a2.p = dy; L.a2.N = N; L.a2.Cb = Cout / 8; L.a2.C = Cout; L.a2.Z = 2; L.a2.H = So; L.a2.W = So;
+    L.a2.nstride = (long)(Cout / 8) * voxo * 8;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipError_t e = (f16 ? launch_conv27_f16 : launch_conv27_bf16)(L, st);
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters && e == hipSuccess; ++i) e = (f16 ? launch_conv27_f16 : launch_conv27_bf16)(L, st);
+  (void)hipEventRecord(e1, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  *ms_per_launch = 0.f;
+  if (e == hipSuccess && e2 == hipSuccess) { (void)hipEventElapsedTime(ms_per_launch, e0, e1); *ms_per_launch /= (float)iters; }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(dw); (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(df);
+  if (dr) (void)hipFree(dr);
+  if (e != hipSuccess) return fail(TM_ERR_HIP, "launch_conv27 (16-bit): %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(TM_ERR_HIP, "conv27 (16-bit) execution: %s", hipGetErrorString(e2));
+  return TM_OK;
 }
 extern "C" int tm_op_conv1_bf16(const void* x_cb8, const void* w_host, const void* bias_host, void* y_cb8, int N, int Cin,
                                 int Cout, int Z, int S, int gelu, int dtype, int waves, const void* res_h16, const void* gate_h16,

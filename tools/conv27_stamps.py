@@ -39,7 +39,7 @@ def main():
         m(**kw)
     torch.cuda.synchronize()
     cap = 400_000
-    buf = torch.zeros((cap, 8), dtype=torch.int64, device=dev)
+    buf = torch.zeros((cap, 16), dtype=torch.int64, device=dev)
     assert L.tm_diag_stamps(C.c_void_p(buf.data_ptr()), cap) == 0
     m(**kw)
     torch.cuda.synchronize()
