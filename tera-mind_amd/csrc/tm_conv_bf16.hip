@@ -451,12 +451,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
 
-  // zero both activation images once (conv zero padding + slots past the tile)
-  for (int i = tid; i < G::XPIECES; i += NT) {
-    lds16[G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
-    lds16[G::BUF16 + G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
-  }
-  __syncthreads();
+  // (no zero fill of the activation images: out-of-range lanes of `buffer_load ... lds` write zeros, see conv27_pp)
 
   // one stage = (channel-block pair, input plane zi): global -> LDS by LDS-DMA, no staging registers.  Output plane zo
   // reads the input planes [zo-1, zo+1] that exist (kz = zi + 1 - zo): 2 of 3 for the z_size-2 checkpoint model, 1 for
@@ -771,12 +766,9 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ct][mt][r] = 0.f;
 
-  for (int i = tid; i < G::XPIECES; i += NT) {
-    lds16[G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
-    lds16[G::BUF16 + G::WPIECES + i] = u32x4{0u, 0u, 0u, 0u};
-  }
-  __syncthreads();
-
+  // No zero fill of the activation images: a lane whose halo slot lies outside the plane / patch carries an out-of-range offset,
+  // and an out-of-range lane of `buffer_load ... lds` WRITES ZEROS to its LDS slot (checked on gfx950 with the images prefilled
+  // with NaNs: every bit-exact op test still passes) -- every slot a tap reads is rewritten by every stage.
   const int zi0 = UPS ? 0 : (zo > 0 ? zo - 1 : 0);
   const int npl = UPS ? 1 : (zo + 2 < a.Z ? zo + 2 : a.Z) - zi0;      // stages per channel-block pair
   const int NH = npl * ah.Cbp;
@@ -797,14 +789,9 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
   constexpr typename SCH::Tbl sch = SCH::make();       // which pieces go with which load step
   static_assert(NP <= 16 && NSEG <= 4, "schedule table shape");
 
-  // prologue: stages 0 and 1 into the two buffers, all of it landed before the first read
+  // prologue: stage 0 into buffer 0, landed before the first read (stage 1 arrives through the load steps of stage 0)
 #pragma unroll
   for (int p = 0; p < NP; ++p) issue_piece(lds16, 0, zi0, p);
-  if (NH > 1) {
-    const int c1 = 1 / npl, z1 = zi0 + 1 % npl;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) issue_piece(lds16 + G::BUF16, c1, z1, p);
-  }
   __syncthreads();                                     // vmcnt(0) + barrier
   TM_STAMP(1);
 #ifdef TM_STAMPS
@@ -812,17 +799,6 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
 #endif
 
   bf16x8 wf[SEGT][2], xf[SEGT][4];
-  auto loadseg = [&](const u32x4* b, int j) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < SEGT; ++t) {
-      const int tap = j * SEGT + t;
-      const int xd = tap_xd(tap);
-      wf[t][0] = __builtin_bit_cast(bf16x8, b[tap * TN * 2 + wb]);
-      wf[t][1] = __builtin_bit_cast(bf16x8, b[tap * TN * 2 + 64 + wb]);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) xf[t][mt] = __builtin_bit_cast(bf16x8, b[xb[mt] + xd]);
-    }
-  };
   // coordinates of the stage whose pieces are being issued: the stage after the one whose segments are being loaded
   int f_cbp = (NH > 1) ? 1 / npl : 0, f_zi = zi0 + ((NH > 1) ? 1 % npl : 0);
   // load step of segment j: (dma) retire this wave's older pieces, then the segment's ds_reads from `rb` tap by tap with this
@@ -848,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
         if (n < sch.cnt[j]) issue_piece(db, f_cbp, f_zi, sch.piece[j][n]);
     }
   };
-  loadseg(lds16, 0);
+  load_step(lds16, 0, NH > 1, lds16 + G::BUF16);       // segment (0, 0) + the first pieces of stage 1
   __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) only
       asm volatile("" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one interval behind group 0
@@ -856,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
 
   for (int hs = 0; hs < NH; ++hs) {
     const bool more = hs + 1 < NH;
-    const bool fetch_cur = hs >= 1 && more;            // load steps 1 .. of stage hs carry pieces of stage hs + 1 (stage 1: the prologue's)
+    const bool fetch_cur = more;                       // load steps 1 .. of stage hs carry pieces of stage hs + 1
     const bool fetch_next = hs + 2 < NH;               // load step 0 of stage hs + 1 (end of this iteration): pieces of stage hs + 2
     u32x4* buf = lds16 + (hs & 1) * G::BUF16;
     u32x4* nbuf = lds16 + ((hs + 1) & 1) * G::BUF16;

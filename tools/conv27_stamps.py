@@ -38,7 +38,7 @@ def main():
     for _ in range(2):
         m(**kw)
     torch.cuda.synchronize()
-    cap = 400_000
+    cap = 800_000
     buf = torch.zeros((cap, 16), dtype=torch.int64, device=dev)
     assert L.tm_diag_stamps(C.c_void_p(buf.data_ptr()), cap) == 0
     m(**kw)
@@ -46,6 +46,8 @@ def main():
     n = L.tm_diag_stamp_count()
     L.tm_diag_stamps(None, 0)
     a = buf[:min(n, cap)].cpu().numpy()
+    # the ping-pong kernel stamps lane 0 of wave 0 AND of wave 4 (tag + 4): keep wave 0's slots for this table
+    a = a[((a[:, 6] % 10) // 4) == 0]
     # split into launches: consecutive slots with the same (grid, tag) up to `grid` entries
     out, i = [], 0
     while i < len(a):
