@@ -20,6 +20,10 @@ diffusion step ends with the 32-px halo-strip exchange with the neighbouring ran
 scaling: the ROI is the same for every N.  Reported: interior patch-steps/s of the whole job, per-step exchange time
 and bytes, and the world size as RCCL sees it.
 
+The default line also carries `sweep.roofline` (the 16-bit conv kernel's executed TFLOP/s, fraction of the dense peak and
+counter traffic during the sweep's timed steps) and `extra.tile_<dtype>`: the stacked one-tile step (BASELINE config 4's
+governing shape) on the sweep's packed model, 3 timed steps, with its own `roofline`.
+
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, the 3x3x3 implicit-GEMM conv: MFMA FLOPs actually
 issued per launch / average launch duration from hipEvents recorded on the launch stream during the timed region,
 against the dense MFMA peak of the dtype) and `cpu_baseline` (oracle/teramind_cpu.py on the host cores, bounded sample).
@@ -179,6 +183,10 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     digest = [int(v) for v in dig.cpu()]
     tiles = args.sweep_hnm * args.sweep_wnm
     value = 400.0 * tiles * steps / res["dt"]
+    # a whole T-step sweep = its first step (which also computes what the later steps reuse: level 0 of the RNA conditioning
+    # with cache_level0, workspace set-up) + T - 1 steady steps
+    first_s = launch.reduce_max([res["warmup_s"][0]], dev)[0] if res["warmup_s"] else None
+    steady_s = res["dt"] / steps
     out = {"value": round(value, 3), "unit": "interior patch-steps/s", "scaling": "strong", "dtype": args.sweep_dtype,
            "workload": (f"fixed ROI of {args.sweep_hnm} x {args.sweep_wnm} test_brn tiles (256x256 px x 100 channels = 25 z-chunks x "
                         f"16 interior patches, P=4) per diffusion step, DDIM-15 schedule, {args.sweep_dtype} UNet arithmetic, one "
@@ -192,13 +200,56 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
            # level 0 of the RNA conditioning (gene attention -> down_z) kept per model call from the first step of the sweep on (the
            # warm-up step here): the timed steps are steps 2 .. T of a sweep, the first one costs ~2.5 % more
            "cache_level0": bool(args.sweep_cache_level0),
+           "first_step_s": round(first_s, 4) if first_s is not None else None,
+           "value_full_sweep": (round(400.0 * tiles * T / (first_s + (T - 1) * steady_s), 3) if first_s is not None else None),
+           "value_full_sweep_note": f"patch-steps/s of a whole T = {T} sweep = 400 x tiles x T / (measured first step + (T - 1) x measured steady step)",
            "s_per_tile_step_per_gpu": round(res["dt"] / steps / max(1, -(-args.sweep_hnm // world) * args.sweep_wnm), 5),
            "world_size_rccl": res["world"], "backend": res["backend"],
            "exchange_ms_per_step": round(res["exchange_ms_per_step"], 3),
            "exchange_bytes_per_step_per_rank": res["exchange_bytes_per_step"],
            "weights_broadcast_bytes": int(model.arena().numel()) if world > 1 else 0,
            "rows_rank0": list(res["rows"]), "state_digest": digest}
-    return out, prof, res["dt"], value
+    return out, prof, res["dt"], value, model, cfg
+
+
+def tile_extra(model, cfg, dev, dtype, steps=3, warmup=1):
+    """The stacked one-tile step in the sweep's arithmetic (BASELINE config 4's governing shape: 25 z-chunks x 5x5 padded
+    patches, P = 4) on the model the sweep packed: pad+patchify -> UNet -> DDIM update, `steps` timed steps."""
+    import torch
+    from teramind_amd import synth
+    from teramind_amd.diffusion import SpacedDiffusionBeatGans, pad_patchify, sampler_step
+    b, P, C, ps = 25, 4, cfg.in_channels, cfg.patch_size
+    smp = SpacedDiffusionBeatGans(T_STEPS, "ddim")
+    ne = b * (P + 1) ** 2
+    state = synth.normal("bench/tile/xT", (b, C, ps * P, ps * P), 7).to(dev)
+    rna = synth.gene_counts("bench/tile/rna", (ne, cfg.gn_sz, cfg.gn_sz, cfg.rna_slc * 500), 7).to(dev)
+    shape_only = torch.empty((b, C, ps * P, ps * P), device="meta")
+    tmap = torch.tensor(smp.timestep_map, dtype=torch.int64, device=dev)
+
+    def one_step(k, st):
+        i = T_STEPS - 1 - k
+        xp = pad_patchify(st, ps)
+        eps = model(x=xp, t=tmap[i].expand(b).contiguous(), rna=rna, imgs=shape_only, patch_size=ps).pred
+        return sampler_step(smp, i, xp, eps, None, b, P, P)
+
+    for k in range(warmup):
+        state = one_step(k, state)
+    torch.cuda.synchronize()
+    model.profile(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        state = one_step(warmup + k, state)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = model.profile_collect()
+    model.profile(False)
+    assert torch.isfinite(state).all(), "non-finite state"
+    value = b * P * P * steps / dt
+    return {"workload": "one test_brn tile per step: 25 z-chunks x (5x5 padded -> 4x4 interior) patches (P=4, 625 padded + 400 collage "
+                        "patches), DDIM T=50 schedule, mode B arithmetic, " + dtype,
+            "dtype": dtype, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+            "value": round(value, 3), "unit": "interior patch-steps/s",
+            "roofline": roofline_block(prof, dtype, dt, value, P, True)}
 
 
 def worker(args):
@@ -304,7 +355,15 @@ def worker(args):
     sweep_steps, sweep_warm = (args.steps, args.warmup) if args.sweep else (args.sweep_steps, 1)
     if args.sweep or not args.no_sweep:
         torch.cuda.empty_cache()
-        sw_out, sw_prof, sw_dt, sw_value = run_sweep_bench(args, dev, sd, world, rank, sweep_steps, sweep_warm)
+        sw_out, sw_prof, sw_dt, sw_value, sw_model, sw_cfg = run_sweep_bench(args, dev, sd, world, rank, sweep_steps, sweep_warm)
+        # the 16-bit roofline belongs in the driver's line: the sweep's own conv27 figures, and the stacked one-tile step
+        # (config 4's governing shape) on the same packed model
+        sw_roof = roofline_block(sw_prof, args.sweep_dtype, sw_dt, sw_value / world, 4, True, sweep=True)
+        extra = None
+        if not args.sweep and not args.no_tile_extra:
+            torch.cuda.empty_cache()
+            extra = tile_extra(sw_model, sw_cfg, dev, args.sweep_dtype)
+        del sw_model
         if rank == 0 and args.sweep:
             out = {"metric": "denoising steps/sec on 64x64x(2 stains x 2 z) patches (interior patch-steps/s)",
                    "value": sw_out["value"], "unit": "interior patch-steps/s", "n_gpus": world, "steps": sweep_steps,
@@ -313,10 +372,13 @@ def worker(args):
                    "data": "synthetic (hashed weights seed 0, per-tile seeded N(0,1) initial state, sparse integer gene tiles)",
                    "config": {"workload": sw_out["workload"], "parallelism": f"row-sharded tile grid over {world} rank(s), "
                               "32-px halo-strip exchange per step (RCCL send/recv), weight arena broadcast once"},
-                   "roofline": roofline_block(sw_prof, args.sweep_dtype, sw_dt, sw_value / world, 4, True, sweep=True),
+                   "roofline": sw_roof,
                    "sweep": sw_out}
         elif rank == 0:
+            sw_out["roofline"] = sw_roof
             out["sweep"] = sw_out
+            if extra is not None:
+                out["extra"] = {"tile_" + args.sweep_dtype: extra}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the host cores are shared at N>1)
             out["cpu_baseline"] = cpu_baseline(PathConfig(), sd)
@@ -339,6 +401,7 @@ def main():
     ap.add_argument("--sweep", action="store_true",
                     help="measure ONLY the row-sharded tile sweep (strong scaling; --steps / --warmup are diffusion steps of the ROI)")
     ap.add_argument("--no-sweep", action="store_true", help="default mode: skip the short sweep appended as the `sweep` object")
+    ap.add_argument("--no-tile-extra", action="store_true", help="default mode: skip the stacked one-tile 16-bit step appended as `extra`")
     ap.add_argument("--sweep-hnm", type=int, default=8)
     ap.add_argument("--sweep-wnm", type=int, default=8)
     ap.add_argument("--sweep-steps", type=int, default=2, help="timed diffusion steps of the appended sweep (1 warm-up step)")

@@ -85,6 +85,7 @@ class TileSweep:
         self.batch_rows = max(1, int(batch_rows)) if self.share_halo else 1
         self.cache_level0 = bool(cache_level0) and hasattr(model, "precompute_rna_level0")
         self._level0 = {}
+        self._overlap_checked = set()                    # share_halo windows whose gene tiles were checked for agreement
         self.r0, self.r1 = tiles.row_block_partition(hnm, world)[rank]
         self.nrows = self.r1 - self.r0
         H = self.nrows * tiles.TILE + 2 * PAD
@@ -234,8 +235,16 @@ class TileSweep:
             blk = ps // conf.gn_sz                                            # pixels per gene cell
             hc, ic = PAD // blk, tiles.TILE // blk                           # halo / interior cells per tile side
             bands = []
+            grid = [[self.gene(self.row0 + self.r0 + lr + i, self.col0 + c0 + j).to(self.dev) for j in range(k)] for i in range(nr)]
+            if key not in self._overlap_checked:
+                # One window per call keeps every tile's interior cells and the edge tiles' halo: that equals the reference's
+                # per-tile calls (utils/MBADataset_tst.py:65-89: every tile brings its own 4-cell halo) only if neighbouring
+                # tiles AGREE on the 2 * hc cells they both hold -- true for tiles cut with overlap from one gene map, checked
+                # here once per window instead of assumed.
+                self._check_gene_overlap(grid, lr, c0, hc, ic)
+                self._overlap_checked.add(key)
             for i in range(nr):                                               # one band of cell rows per tile row
-                gts = [self.gene(self.row0 + self.r0 + lr + i, self.col0 + c0 + j).to(self.dev) for j in range(k)]
+                gts = grid[i]
                 band = torch.cat([gts[0][:, :hc]] + [g[:, hc:hc + ic] for g in gts] + [gts[-1][:, hc + ic:]], dim=1)
                 r0 = 0 if i == 0 else hc                                      # outer halo rows from the window's edge tiles
                 r1 = hc + ic + (hc if i == nr - 1 else 0)
@@ -245,6 +254,22 @@ class TileSweep:
         out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
                                   patch_size=ps, idx=self.T - epoch - 1, model_kwargs=None)
         return tiles.regroup_output(out, 1, self.n_stain)[0]
+
+    def _check_gene_overlap(self, grid, lr, c0, hc, ic):
+        """share_halo precondition: the gene tiles of a window agree on the cells neighbouring tiles both hold."""
+        nr, k = len(grid), len(grid[0])
+        name = lambda i, j: f"tile (row {self.row0 + self.r0 + lr + i}, col {self.col0 + c0 + j})"
+        for i in range(nr):
+            for j in range(k):
+                g = grid[i][j]
+                if j + 1 < k and not torch.equal(g[:, ic:ic + 2 * hc], grid[i][j + 1][:, :2 * hc]):
+                    raise ValueError(f"share_halo: gene {name(i, j)} and {name(i, j + 1)} disagree on the {2 * hc} cell columns they "
+                                     "share; one window per call would drop one tile's version and differ from the reference's "
+                                     "per-tile result -- use share_halo=False for tiles that were not cut from one gene map")
+                if i + 1 < nr and not torch.equal(g[ic:ic + 2 * hc, :], grid[i + 1][j][:2 * hc, :]):
+                    raise ValueError(f"share_halo: gene {name(i, j)} and {name(i + 1, j)} disagree on the {2 * hc} cell rows they "
+                                     "share; one window per call would drop one tile's version and differ from the reference's "
+                                     "per-tile result -- use share_halo=False for tiles that were not cut from one gene map")
 
     def _remember_level0(self, key, rna, shape):
         """cache_level0: level 0 of the RNA conditioning of this call's genes, kept for the following steps."""

@@ -140,6 +140,7 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
     """`main` + `Tester.test` of the reference (test_brn.py:232-295) for this rank: build the rank's TileSweep, run
     `warmup` untimed then `steps` timed diffusion steps (each ending with the halo-strip exchange), and return
     {'sweep': TileSweep, 'dt': seconds of the timed steps on this rank (max over ranks when world > 1), 'step_s': [...],
+     'warmup_s': [seconds of each warm-up step on this rank],
      'exchange_ms_per_step', 'exchange_bytes_per_step', 'world', 'backend', 'rows': (r0, r1)}.
     The timed region is bracketed by a barrier + device synchronise on both sides."""
     import torch
@@ -172,8 +173,13 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
         if cuda:
             torch.cuda.synchronize(dev)
 
+    warm_s = []                                                  # the first step of a sweep also computes what later steps reuse
     for _ in range(warmup):
+        t1 = time.perf_counter()
         sw.step()
+        if cuda:
+            torch.cuda.synchronize(dev)
+        warm_s.append(time.perf_counter() - t1)
     fence()
     if after_warmup is not None:
         after_warmup()
@@ -194,6 +200,6 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
     dt = time.perf_counter() - t0
     exch_ms = 1e3 * sw.exchange_s / max(1, steps)
     dt, exch_ms = reduce_max([dt, exch_ms], dev)
-    return {"sweep": sw, "dt": dt, "step_s": step_s, "exchange_ms_per_step": exch_ms,
+    return {"sweep": sw, "dt": dt, "step_s": step_s, "warmup_s": warm_s, "exchange_ms_per_step": exch_ms,
             "exchange_bytes_per_step": sw.exchange_bytes // max(1, steps), "world": dist.get_world_size() if dist_on else 1,
             "backend": dist.get_backend() if dist_on else "none", "rows": (sw.r0, sw.r1)}

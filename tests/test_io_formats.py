@@ -181,3 +181,66 @@ def test_sweep_save_and_resume_from_step_dir(tmp_path, state):
     assert torch.equal(a.local_state(), b.local_state())       # state is fp16-representable after every step
     with pytest.raises(ValueError):
         TileSweep(cfg, _ToySampler(), None, genes, **kw).save_step(tmp_path / "x")
+
+
+# ---- the reference's own _pad_gn / _pad_im(step > 0) (oracle/make_io_ref_golden.py) ------------------------------------
+REF_PAD = np.load(os.path.join(util.GOLDEN, "io_ref_pad.npz"))
+GN_CASES = ["interior", "roi_corner", "asym_blk8", "spad3_blk16"]
+
+
+def ref_pad_gn_dense(name):
+    """Dense [gsz, gsz, C] tensor of the COO triple the reference's `_pad_gn` returned (duplicates add, as to_dense does)."""
+    dat, crd, ssz = REF_PAD[f"gn/{name}/out_dat"], REF_PAD[f"gn/{name}/out_crd"], REF_PAD[f"gn/{name}/out_ssz"]
+    out = np.zeros(tuple(int(v) for v in ssz), dtype=np.float32)
+    np.add.at(out, (crd[0], crd[1], crd[2]), dat.astype(np.float32))
+    return out
+
+
+@pytest.mark.parametrize("name", GN_CASES)
+def test_gene_tile_shift_and_crop_vs_reference_pad_gn(name):
+    """oracle.gene_tile_dense and formats.gene_tile_shift against MBADataset_tst._pad_gn ITSELF (utils/MBADataset_tst.py:80-89,
+    run on a stand-in COO object): interior tile, padded ROI clipped at the slide corner, asymmetric offset with 8-px
+    cells, 3-slice z padding."""
+    gblk, pad, size, spad, slc, H, W = (int(v) for v in REF_PAD[f"gn/{name}/params"])
+    r = [int(v) for v in REF_PAD[f"gn/{name}/roi"]]
+    roi, roio = r[:4], r[4:]
+    pix, data = REF_PAD[f"gn/{name}/pix"], REF_PAD[f"gn/{name}/data"]
+    ref = ref_pad_gn_dense(name)
+    got = tc.gene_tile_dense(data, pix, (H, W, slc * 500), roi, roio, gblk=gblk, pad=pad, size=size, spad=spad)
+    assert got.shape == ref.shape and np.array_equal(got, ref) and ref.sum() > 0
+    # the product's shift rule: every kept entry of the reference sits at cell (pixel // gblk + shift)
+    sh, sw = formats.gene_tile_shift(roi, roio, gblk, pad)
+    gsz = (size + 2 * pad) // gblk
+    ch, cw = pix[0] // gblk + sh, pix[1] // gblk + sw
+    keep = (ch >= 0) & (ch < gsz) & (cw >= 0) & (cw < gsz)
+    mine = np.zeros_like(ref)
+    np.add.at(mine, (ch[keep], cw[keep], pix[2][keep] + spad * 500), data[keep].astype(np.float32))
+    assert np.array_equal(mine, ref)
+
+
+def _ref_state_tile(row, col, chn, size=256):
+    """oracle/make_io_ref_golden.state_tile: what the stubbed zarr.load returned for tile (row, col)."""
+    c, h, w = np.meshgrid(np.arange(chn), np.arange(size) // 32, np.arange(size) // 32, indexing="ij")
+    return (((row * 5 + col) * 64 + c * 8 + h) / 64.0 - 2.0 + w / 1024.0).astype(np.float16)
+
+
+@pytest.mark.parametrize("state", ["fp32x2", "fp16"])
+def test_halo_assembly_at_later_steps_vs_reference_pad_im(state):
+    """TileSweep._window at epoch > 0 (the 320 x 320 padded tile cut from the resident canvas) == the reference's
+    MBADataset_tst._pad_im(roi, 2) (utils/MBADataset_tst.py:91-123) reading the previous step's 3 x 3 neighbour tiles --
+    centre, corner and edge tiles of a 3 x 3 ROI (outside the ROI: -1), both canvas layouts."""
+    chn, hst, wst, hnm, wnm, step = (int(v) for v in REF_PAD["im/params"])
+    # (3 slices x 2 stains: the per-slice model, rna_slc 1, takes any slice count; the window assembly does not depend on it)
+    sw = TileSweep(PathConfig(rna_slc=1), sampler=None, model=None, gene_provider=None, hst=hst * 256, wst=wst * 256, hnm=hnm,
+                   wnm=wnm, total_epochs=15, total_slc=chn // 2, state=state)
+    assert sw.chn == chn
+    for lr in range(hnm):
+        for c in range(wnm):
+            sw._centre(sw.cur, lr, c).copy_(torch.from_numpy(_ref_state_tile(hst + lr, wst + c, chn).astype(np.float32)))
+    sw.epoch = step
+    sw._strips = {}
+    sw._exchange(sw.cur)
+    for key in [k for k in REF_PAD.files if k.startswith("im/") and k != "im/params"]:
+        lr, c = (int(v) for v in key[3:].split("_"))
+        ref = torch.from_numpy(REF_PAD[key].astype(np.float32))
+        assert torch.equal(sw._window(lr, c).float(), ref), key

@@ -22,18 +22,10 @@ sys.path.insert(0, ROOT)
 
 
 def make_gene_dir(gdir, hnm, wnm, nnz, hst=256, wst=256):
-    """Synthetic COO gene tiles in the reference's on-disk format (utils/MBADataset_tst.py:65-79 reads them)."""
-    import numpy as np
-    from teramind_amd import formats
-    os.makedirs(gdir, exist_ok=True)
-    for r in range(hst // 256, hst // 256 + hnm):
-        for c in range(wst // 256, wst // 256 + wnm):
-            rng = np.random.default_rng(1_000_003 * r + c)
-            shape = (512, 512, 50 * 500)
-            crd = np.stack([rng.integers(0, 512, nnz), rng.integers(0, 512, nnz), rng.integers(0, shape[2], nnz)]).astype(np.int64)
-            data = rng.integers(1, 4, nnz).astype(np.uint16)
-            v = (r * 256, r * 256 + 256, c * 256, c * 256 + 256, r * 256 - 128, r * 256 + 384, c * 256 - 128, c * 256 + 384)
-            formats.write_gene_npz(os.path.join(gdir, "_".join(map(str, v)) + ".npz"), data, crd, shape)
+    """Synthetic COO gene tiles in the reference's on-disk format, cut from ONE gene map (synth.write_gene_tile_dir): tiles that
+    overlap agree, so --share_halo is legitimate on them (TileSweep checks it)."""
+    from teramind_amd import synth
+    synth.write_gene_tile_dir(gdir, hnm, wnm, max(1, nnz // 16), hst=hst, wst=wst)
 
 
 def worker(args):
