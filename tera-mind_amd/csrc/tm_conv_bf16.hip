@@ -1685,16 +1685,18 @@ void conv1_bf16_pack_host(const float* w /*[Cout][Cin]*/, int Cout, const int* s
 }
 
 static const void* zero_page(hipError_t* err) {
-  static void* zp[128] = {nullptr};                     // 256 B of zeros per device, lives for the process
+  static std::atomic<void*> zp[128];                    // 256 B of zeros per device, lives for the process
   const int d = DevOnce::dev();
-  if (!zp[d]) {
+  if (d < 0 || d >= 128) { *err = hipErrorInvalidDevice; return nullptr; }
+  if (!zp[d].load()) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, 256);
     if (e == hipSuccess) e = hipMemset(p, 0, 256);
     if (e != hipSuccess) { *err = e; return nullptr; }
-    zp[d] = p;
+    void* expect = nullptr;
+    if (!zp[d].compare_exchange_strong(expect, p)) (void)hipFree(p);       // another thread was first
   }
-  return zp[d];
+  return zp[d].load();
 }
 #ifdef TM_H16_F16
 hipError_t init_f16_device() {

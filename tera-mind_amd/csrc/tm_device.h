@@ -2,6 +2,7 @@
 #pragma once
 #include "tm_kernels.h"
 #include <math.h>
+#include <atomic>
 
 namespace tmk {
 
@@ -11,12 +12,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TM_EPS 1e-6f
 
 // Host-side once-per-DEVICE flag for lazy launch setup (hipFuncSetAttribute applies to the current device's code
-// object, so a per-process `static bool` would leave every device but the first without its LDS limit).
+// object, so a per-process `static bool` would leave every device but the first without its LDS limit).  Safe to use from
+// several host threads that drive different devices / streams: the bits are set with an atomic OR (a set-up that two
+// threads both find undone is simply performed twice; hipFuncSetAttribute is idempotent).  A failing hipGetDevice, or a
+// device index past the 128 the flag words cover, reports "not done" and marks nothing: the set-up then runs on every
+// launch and ITS hip call returns the error.
 struct DevOnce {
-  unsigned long long done[2] = {0ull, 0ull};           // devices 0..127
-  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 127; }
-  bool need() const { const int d = dev(); return !((done[d >> 6] >> (d & 63)) & 1ull); }
-  void mark() { const int d = dev(); done[d >> 6] |= 1ull << (d & 63); }
+  std::atomic<unsigned long long> done[2] = {{0ull}, {0ull}};      // devices 0..127
+  static int dev() { int d = -1; return hipGetDevice(&d) == hipSuccess ? d : -1; }
+  bool need() const {
+    const int d = dev();
+    if (d < 0 || d >= 128) return true;
+    return !((done[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1ull);
+  }
+  void mark() {
+    const int d = dev();
+    if (d >= 0 && d < 128) done[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release);
+  }
 };
 #ifndef TM_H16_T
 #define TM_H16_T __bf16          // 16-bit float type of the y_h / gate_h tensors in this translation unit (tm_conv_bf16.hip)

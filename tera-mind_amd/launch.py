@@ -56,7 +56,11 @@ def spawn_ranks(n: int, argv: Sequence[str], port: Optional[int] = None, env: Op
         e.update(env or {})
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this host driver
+        # The caller's environment decides; only when it says nothing, pick dmabuf IPC: this image's environment notes state that
+        # the host driver supports dmabuf IPC only and that RCCL / cross-process device-memory sharing fails with
+        # `hipIpcGetMemHandle: invalid argument` under the legacy mode (the image itself exports the variable as 0).  Not
+        # verified by a multi-GPU run of this repository: no multi-GPU box was available to it.
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([python or sys.executable] + list(argv), env=e))
     deadline = None if timeout is None else time.monotonic() + timeout
     rc = 0

@@ -51,3 +51,18 @@ def test_default_bench_line_with_two_ranks_rehearsed():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["value"] > 0
     assert d["config"]["per_gpu_patches_per_step"] == 32 and 0 < d["roofline"]["frac"] <= 1.0
     assert d["sweep"]["world_size_rccl"] == 2 and d["sweep"]["scaling"] == "strong" and "cpu_baseline" not in d
+
+
+def test_two_rank_sweep_over_rccl_equals_single_process():
+    """The real thing, for the first lease that has two GPUs: `bench.py --gpus 2 --sweep` with one rank per GPU over RCCL
+    (backend "nccl": arena broadcast on device, batch_isend_irecv strip exchange, on-device reductions).  Skipped on the
+    one-GPU boxes this repository has been developed on -- where it has therefore never run."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    one = _bench(["--gpus", "1"])
+    two = _bench(["--gpus", "2"])
+    s1, s2 = one["sweep"], two["sweep"]
+    assert s2["world_size_rccl"] == 2 and s2["backend"] == "nccl" and s2["rows_rank0"] == [0, 1]
+    assert s1["state_digest"] == s2["state_digest"]
+    assert s2["exchange_bytes_per_step_per_rank"] == 2 * 100 * 32 * (2 * 256 + 64) * 2
