@@ -71,6 +71,7 @@ struct ConvArgsH {
   // out_layers[0] RMSNorm(C) * w -> x(1+scale)+shift -> SiLU (MBAblocks.py:196-203,356-367) written as the bf16
   // input of the second conv; the fp32 conv output itself is not stored.
   int fuse;
+  int bid0;                   // conv27: first tile id of this launch (a launch may cover a sub-range of the layer's tiles)
   const float* norm_w; const float* mod_scale; const float* mod_shift;
   long mod_stride; int per_image; float inv_c;
   uint16_t* a2; long a2_nstride;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
   const int S = a.S;
   const int tiles_c = S / TW, tiles_r = S / G::TR;
   const int tiles = tiles_c * tiles_r;
-  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int bid = ah.bid0 + xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;                        // n-tile of TN couts
   int mt_ = bid / a.ntile;
   int py = 0, px = 0;                                  // UPS: output phase (the four phases of a tile are grid neighbours)
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
   const int S = a.S;
   const int tiles_c = S / TW, tiles_r = S / G::TR;
   const int tiles = tiles_c * tiles_r;
-  const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int bid = ah.bid0 + xcd_swizzle(blockIdx.x, gridDim.x);
   const int nt = bid % a.ntile;
   int mt_ = bid / a.ntile;
   int py = 0, px = 0;
@@ -1738,7 +1739,7 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = L.flags;
   a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
   a.res_h = L.res_h ? L.res_h->p : nullptr; a.res_h_nstride = L.res_h ? L.res_h->nstride : 0;
-  ah.fuse = 0;
+  ah.fuse = 0; ah.bid0 = 0;
   ah.x_nstride_e = L.x.nstride; ah.x_plane_e = (long)L.x.Z * L.x.H * L.x.W * 8; ah.Cbp = L.x.Cb / 2;
   ConcatX cx;
   cx.nsrc = L.nsrc; cx.p1 = L.p1; cx.p2 = L.p2; cx.cbtot = 0;
@@ -1793,6 +1794,19 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
   return hipGetLastError();
 }
 
+// compute units of the current device (workgroups of the 8-wave conv form that run at once), cached per device
+static long cu_count() {
+  static std::atomic<int> cus[128];
+  const int d = DevOnce::dev();
+  if (d < 0 || d >= 128) return 256;
+  int c = cus[d].load();
+  if (!c) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c < 1) c = 256;
+    cus[d].store(c);
+  }
+  return c;
+}
+
 hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   ConvArgsH ah;
   ConvArgs& a = ah.c;
@@ -1804,6 +1818,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   a.N = L.x.N; a.S = L.x.H; a.Z = L.x.Z; a.Cbi = L.x.Cb; a.flags = 0;
   a.y_h = L.y_h; a.yh_nstride = L.yh_nstride;
   a.res_h = L.res_h ? L.res_h->p : nullptr; a.res_h_nstride = L.res_h ? L.res_h->nstride : 0;
+  ah.bid0 = 0;
   ah.fuse = L.fuse_norm; ah.norm_w = L.norm_w; ah.mod_scale = L.mod_scale; ah.mod_shift = L.mod_shift;
   ah.mod_stride = L.mod_stride; ah.per_image = L.per_image; ah.inv_c = 1.0f / (float)L.Cout;
   ah.a2 = L.a2.p; ah.a2_nstride = L.a2.nstride;
@@ -1874,6 +1889,9 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res || L.res_h)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
   static const int env27 = env_waves("TM_CONV27_WAVES");
+  static const int tail_split = [] { const char* e = getenv("TM_CONV27_TAIL_SPLIT"); return e ? atoi(e) : 1; }();     // A/B switch
+  const long ncu = cu_count();
+  long grid_override = 0;
   const int fw27 = L.force_waves == 9 ? 8 : (L.force_waves ? L.force_waves : env27);
   if (fw27 != 0 && fw27 != 4 && fw27 != 8) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
@@ -1882,7 +1900,23 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     const long tiles8 = (long)(S / TW_) * (S / G8::TR);                                         \
     const long grid8 = ((a.N + G8::NPB - 1) / G8::NPB) * a.Z * tiles8 * a.ntile;                \
     const bool w8 = fw27 ? fw27 == 8 : grid8 >= 256;                                            \
-    if (w8 && use_pp) TM_LAUNCHPP(TN_, TW_); else if (w8) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4); \
+    /* TAIL SPLIT (automatic form only).  One 8-wave workgroup fills a CU, so a launch runs in rounds of `ncu` workgroups */ \
+    /* and its last, partial round costs a whole round: 632 tiles on 256 CUs are 3 rounds for 2.47 rounds of work.  When  */ \
+    /* that round would occupy at most half the CUs, its tiles go to a second launch of the 4-wave form instead (half the */ \
+    /* voxels per workgroup, twice the workgroups, still one per CU): the same voxels, outputs and arithmetic per output,   */ \
+    /* finished in about half a round.  The split sits on a patch-group boundary so both forms tile the same voxel set.    */ \
+    using G4 = HGeo<TN_, TW_, 4>;                                                               \
+    const long unit = (long)a.ntile * a.Z * tiles8;                                             \
+    const long full = grid8 / ncu * ncu / unit * unit;                                          \
+    const long grid4 = ((a.N + G4::NPB - 1) / G4::NPB) * a.Z * ((long)(S / TW_) * (S / G4::TR)) * a.ntile; \
+    const long tail4 = grid4 - 2 * full;                                                        \
+    if (w8 && use_pp && fw27 == 0 && tail_split && full >= ncu && tail4 > 0 && tail4 <= ncu) {  \
+      grid_override = full;                                                                     \
+      TM_LAUNCHPP(TN_, TW_);                                                                    \
+      ah.bid0 = (int)(2 * full); grid_override = tail4;                                         \
+      TM_LAUNCHHW(TN_, TW_, 4);                                                                 \
+      ah.bid0 = 0; grid_override = 0;                                                           \
+    } else if (w8 && use_pp) TM_LAUNCHPP(TN_, TW_); else if (w8) TM_LAUNCHHW(TN_, TW_, 8); else TM_LAUNCHHW(TN_, TW_, 4); \
   } while (0)
 #define TM_LAUNCHPP(TN_, TW_)                                                                    \
   do {                                                                                          \
@@ -1898,7 +1932,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     }                                                                                           \
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
-    const long grid = pgs * a.Z * tiles * a.ntile;                                              \
+    const long grid = grid_override ? grid_override : pgs * a.Z * tiles * a.ntile;              \
     if (ah.fuse) hipLaunchKernelGGL((conv27_pp<TN_, TW_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
     else hipLaunchKernelGGL((conv27_pp<TN_, TW_, false>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
   } while (0)
@@ -1916,7 +1950,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     }                                                                                           \
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
-    const long grid = pgs * a.Z * tiles * a.ntile;                                              \
+    const long grid = grid_override ? grid_override : pgs * a.Z * tiles * a.ntile;              \
     if (ah.fuse) hipLaunchKernelGGL((conv27_bf16<TN_, TW_, true, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
     else hipLaunchKernelGGL((conv27_bf16<TN_, TW_, false, NWV_>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
   } while (0)

@@ -152,6 +152,24 @@ def test_conv27_16bit_stream_epilogue(N, Cin, Cout, S, waves, dtype):
     assert torch.equal(got.cpu(), ref), util.report("conv27 stream " + dtype, got, ref)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,S", [(328, 16, 512, 8), (135, 16, 256, 16), (70, 24, 128, 32), (289, 16, 64, 16)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv27_16bit_tail_split_launch(N, Cin, Cout, S, dtype):
+    """Launches whose last round of 8-wave workgroups would occupy at most half the CUs are split: full rounds on the
+    ping-pong 8-wave kernel, the remaining tiles as 4-wave workgroups of half the voxels (launch_conv27_bf16, TAIL SPLIT).
+    Shapes here produce 256 + a short tail of tiles in every tile geometry (patch groups of 8 / 2 / 1, two tile rows, an odd
+    patch count whose last 8-wave group is half empty): the union must be exactly the layer -- bit-exact on integers, with
+    the 16-bit residual / output epilogue."""
+    td = util.H16[dtype][1]
+    x = util.rand_int((N, Cin, 2, S, S), -3, 3, 91)
+    w = util.rand_int((Cout, Cin, 3, 3, 3), -2, 2, 92)
+    b = util.rand_int((Cout,), -4, 4, 93)
+    res = util.rand_int((N, Cout, 2, S, S), -100, 100, 94)
+    ref = (F.conv3d(x, w, b, padding=1) + res).to(td).float()
+    got, _ = util.conv27_bf16(x.to(DEV), w, b, dtype, 0, res=res.to(DEV), out16=True)
+    assert torch.equal(got.cpu(), ref), util.report("conv27 tail split " + dtype, got, ref)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,Z,S", [(2, 229, 1792, 2, 8), (3, 13, 40, 2, 8), (1, 96, 64, 2, 64), (7, 128, 64, 2, 16)])
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
