@@ -36,7 +36,8 @@ class TileSweep:
                  hst: int = 256, wst: int = 256, hnm: int = 32, wnm: int = 32, total_epochs: int = 15,
                  total_slc: int = 50, device="cpu", rank: int = 0, world: int = 1, batch_tiles: int = 1,
                  group=None, init: str = "reference", noise_provider: Optional[Callable] = None,
-                 state: str = "fp32x2", share_halo: bool = False, batch_rows: int = 1, cache_level0: bool = False):
+                 state: str = "fp32x2", share_halo: bool = False, batch_rows: int = 1, cache_level0: bool = False,
+                 z_group: Optional[int] = None):
         """hst/wst/hnm/wnm/total_epochs mirror the test_brn CLI (test_brn.py:302-334).
         gene_provider(row, col) -> dense [20, 20, (total_slc + 2*zpad) * 500] gene tile (already
         block-summed and z-padded like MBADataset_tst._getgene/_pad_gn) for ABSOLUTE tile
@@ -61,6 +62,12 @@ class TileSweep:
                provider does not).  The window's genes: every tile's own 16 x 16 interior cells, the outer halo
                cells from the window's edge tiles.  batch_rows (share_halo only): tile rows per window -- the halo
                ROWS between them are shared the same way ((4 r + 1) x (4 k + 1) encoder patches for r x k tiles).
+        z_group: images (z-chunks of tiles / windows) per MODEL call.  A call of the sweep holds n_z x (tiles or windows) images
+               that never exchange data (test_brn.py:188-197,219-221); the model's workspace is proportional to the images
+               of a call (twelve encoder skip tensors, the RNA pyramid and the widest decoder block's scratch live for the
+               call: 8.8 GiB per tile, 123.8 GiB for a 4 x 4 window in the 16-bit modes).  z_group = g runs a call's images
+               g at a time through the sampler -- the same kernels on the same per-image data, bit-identical -- so that
+               large shared-halo windows fit beside the whole-brain canvas (a 4 x 4 window at g = 5: ~25 GiB).
         cache_level0: keep level 0 of the RNA conditioning (gene attention -> down_z -> Upsample, unet_ours.py:298-310: the
                part that reads the gene counts) of every model call of a step and reuse it in the following steps -- the
                genes of a tile are the same at each of the T steps (test_brn.py:232-255 re-reads and re-embeds them every
@@ -84,6 +91,7 @@ class TileSweep:
         self.share_halo = bool(share_halo)
         self.batch_rows = max(1, int(batch_rows)) if self.share_halo else 1
         self.cache_level0 = bool(cache_level0) and hasattr(model, "precompute_rna_level0")
+        self.z_group = None if not z_group else max(1, int(z_group))
         self._level0 = {}
         self._overlap_checked = set()                    # share_halo windows whose gene tiles were checked for agreement
         self.r0, self.r1 = tiles.row_block_partition(hnm, world)[rank]
@@ -91,7 +99,7 @@ class TileSweep:
         H = self.nrows * tiles.TILE + 2 * PAD
         W = wnm * tiles.TILE + 2 * PAD
         self.epoch = 0
-        self._pending, self._noise_rows, self._strips = {}, {}, {}
+        self._pending, self._noise_tiles, self._noise_cap = {}, {}, 18
         # halo-exchange accounting (bench.py --sweep): seconds (device-synchronised when time_exchange is set), bytes
         # sent + received by this rank, number of exchanges
         self.time_exchange, self.exchange_s, self.exchange_bytes, self.exchanges = False, 0.0, 0, 0
@@ -124,38 +132,45 @@ class TileSweep:
                 t = self._noise_tile(self.row0 + self.r0 + lr, self.col0 + c)
                 self._centre(self.cur, lr, c).copy_(t.permute(2, 0, 1))
 
-    # ---- 'fp16' state: row strips --------------------------------------------------------------
-    def _noise_row(self, lr: int) -> torch.Tensor:
-        """[C, 256, wnm*256] float32 noise of local row lr (may be -1 or nrows: the neighbouring rank's row, or
-        all -1 outside the ROI, MBADataset_tst.py:95-101); a three-row band is kept."""
-        if lr not in self._noise_rows:
-            row = self.r0 + lr                                   # row inside the ROI
-            band = torch.full((self.chn, tiles.TILE, self.wnm * tiles.TILE), -1.0, dtype=torch.float32, device=self.dev)
-            if 0 <= row < self.hnm:
-                for c in range(self.wnm):
-                    t = self._noise_tile(self.row0 + row, self.col0 + c)
-                    band[:, :, c * tiles.TILE:(c + 1) * tiles.TILE].copy_(t.permute(2, 0, 1))
-            self._noise_rows[lr] = band
-            for k in [k for k in self._noise_rows if k < lr - 2 - self.batch_rows]:
-                del self._noise_rows[k]
-        return self._noise_rows[lr]
+    # ---- 'fp16' state: the window a call reads -------------------------------------------------------
+    def _noise_tile_chw(self, row: int, col: int) -> torch.Tensor:
+        """Step-0 tile [C, 256, 256] float32 at ROI position (row, col), through a small LRU (neighbouring windows share two
+        tile columns; anything older is regenerated from its seed)."""
+        key = (row, col)
+        t = self._noise_tiles.pop(key, None)
+        if t is None:
+            t = self._noise_tile(self.row0 + row, self.col0 + col).permute(2, 0, 1).contiguous()
+        self._noise_tiles[key] = t                                  # most recent last
+        while len(self._noise_tiles) > self._noise_cap:
+            self._noise_tiles.pop(next(iter(self._noise_tiles)))
+        return t
 
-    def _strip(self, lr: int, nr: int = 1) -> torch.Tensor:
-        """[C, 256 nr + 64, W] float32: local tile rows lr .. lr + nr - 1 with their 32-px halo, as the step reads them."""
-        if (lr, nr) in self._strips:
-            return self._strips[(lr, nr)]
-        y, hh = lr * tiles.TILE, nr * tiles.TILE
+    def _state_window(self, lr: int, nr: int, c0: int, k: int) -> torch.Tensor:
+        """[C, 256 nr + 64, 256 k + 64] float32: local tile rows lr .. lr + nr - 1, columns c0 .. c0 + k - 1 with their 32-px
+        halo, as the step reads them.  Later steps: a slice of the canvas -- the rows a call reads are not overwritten while
+        their row group is in progress (new rows are committed one row late, _commit_rows).  Step 0: the LCG-seeded noise
+        tiles of the window and of the ring of tiles around it (-1 outside the ROI, utils/MBADataset_tst.py:95-101),
+        regenerated per window: nothing of the size of a tile row is held (a float32 row of the whole brain is 11 GB)."""
+        T_ = tiles.TILE
+        hh, ww = nr * T_ + 2 * PAD, k * T_ + 2 * PAD
         if self.epoch > 0:
-            st = self.cur[:, y:y + hh + 2 * PAD, :].float()
-        else:
-            st = torch.full((self.chn, hh + 2 * PAD, self.cur.shape[2]), -1.0, dtype=torch.float32, device=self.dev)
-            st[:, :PAD, PAD:-PAD] = self._noise_row(lr - 1)[:, -PAD:, :]
-            for i in range(nr):
-                st[:, PAD + i * tiles.TILE:PAD + (i + 1) * tiles.TILE, PAD:-PAD] = self._noise_row(lr + i)
-            st[:, -PAD:, PAD:-PAD] = self._noise_row(lr + nr)[:, :PAD, :]
-        self._strips = {k: v for k, v in self._strips.items() if k[0] >= lr - 1}
-        self._strips[(lr, nr)] = st
-        return st
+            return self.cur[:, lr * T_:lr * T_ + hh, c0 * T_:c0 * T_ + ww].float()
+        self._noise_cap = max(self._noise_cap, 2 * (nr + 2) * (k + 2))
+        win = torch.full((self.chn, hh, ww), -1.0, dtype=torch.float32, device=self.dev)
+        for i in range(-1, nr + 1):
+            row = self.r0 + lr + i                                   # row inside the ROI (a neighbouring rank's row at the edges)
+            if not 0 <= row < self.hnm:
+                continue
+            y0 = PAD + i * T_
+            ya, yb = max(y0, 0), min(y0 + T_, hh)
+            for j in range(-1, k + 1):
+                col = c0 + j
+                if not 0 <= col < self.wnm:
+                    continue
+                x0 = PAD + j * T_
+                xa, xb = max(x0, 0), min(x0 + T_, ww)
+                win[:, ya:yb, xa:xb] = self._noise_tile_chw(row, col)[:, ya - y0:yb - y0, xa - x0:xb - x0]
+        return win
 
     def _commit_rows(self, upto: int):
         """Write the pending new rows <= upto into the canvas (their old values have been consumed)."""
@@ -213,7 +228,7 @@ class TileSweep:
     def _window(self, lr: int, c: int) -> torch.Tensor:
         y, x = lr * tiles.TILE, c * tiles.TILE
         if self.state == "fp16":
-            return self._strip(lr)[:, :, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)
+            return self._state_window(lr, 1, c, 1).permute(1, 2, 0)
         return self.cur[:, y:y + tiles.TILE + 2 * PAD, x:x + tiles.TILE + 2 * PAD].permute(1, 2, 0)     # 'h w c'
 
     def _run_row_window(self, lr: int, c0: int, k: int, epoch: int, nr: int = 1):
@@ -221,7 +236,7 @@ class TileSweep:
         conf = self.conf
         x0, wpx = c0 * tiles.TILE, k * tiles.TILE + 2 * PAD
         if self.state == "fp16":
-            win = self._strip(lr, nr)[:, :, x0:x0 + wpx]
+            win = self._state_window(lr, nr, c0, k)
         else:
             y = lr * tiles.TILE
             win = self.cur[:, y:y + nr * tiles.TILE + 2 * PAD, x0:x0 + wpx]
@@ -251,9 +266,30 @@ class TileSweep:
                 bands.append(band[r0:r1])
             rna = tiles.patchify_hwc(tiles.zchunk_rna(torch.cat(bands, dim=0)[None], conf.rna_slc), conf.gn_sz, False)
             rna = self._remember_level0(key, rna, shape)
-        out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
-                                  patch_size=ps, idx=self.T - epoch - 1, model_kwargs=None)
+        out = self._sample(shape, x, rna, ps, epoch)
         return tiles.regroup_output(out, 1, self.n_stain)[0]
+
+    def _sample(self, shape, x, rna, ps, epoch):
+        """sampler.sample (test_brn.py:209-217) on the images of a call, z_group at a time: images are independent, so the
+        groups' results concatenated equal the one call's bit for bit; the model workspace is that of one group."""
+        n = shape[0]
+        g = self.z_group
+        if not g or g >= n:
+            return self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna, patch_size=ps,
+                                       idx=self.T - epoch - 1, model_kwargs=None)
+        pp = x.shape[0] // n                                              # padded patches per image
+        outs = []
+        for i0 in range(0, n, g):
+            i1 = min(n, i0 + g)
+            if hasattr(rna, "buf"):                                           # RnaLevel0: patch-major buffer of equal slices
+                per = rna.buf.numel() // (rna.b * rna.p1 * rna.p2)
+                r = type(rna)(rna.buf[i0 * pp * per:i1 * pp * per], i1 - i0, rna.p1, rna.p2)
+            else:
+                r = rna[i0 * pp:i1 * pp]
+            outs.append(self.sampler.sample(model=self.model, shape=(i1 - i0,) + tuple(shape[1:]), imgs=x[i0 * pp:i1 * pp],
+                                            noise=x[i0 * pp:i1 * pp], r_start=r, patch_size=ps, idx=self.T - epoch - 1,
+                                            model_kwargs=None))
+        return torch.cat(outs)
 
     def _check_gene_overlap(self, grid, lr, c0, hc, ic):
         """share_halo precondition: the gene tiles of a window agree on the cells neighbouring tiles both hold."""
@@ -313,8 +349,7 @@ class TileSweep:
             xz = tiles.zchunk_state(tile_hwc, self.total_slc, conf.rna_slc)
             shape = (xz.shape[0], xz.shape[3], xz.shape[1] - conf.patch_size, xz.shape[2] - conf.patch_size)
             x = tiles.patchify_hwc(xz, conf.patch_size, True)
-        out = self.sampler.sample(model=self.model, shape=shape, imgs=x, noise=x, r_start=rna,
-                                  patch_size=conf.patch_size, idx=self.T - epoch - 1, model_kwargs=None)
+        out = self._sample(shape, x, rna, conf.patch_size, epoch)
         out = tiles.regroup_output(out, len(tile_list), self.n_stain)
         if self.state == "fp16":
             out = out.half()                                                  # test_brn.py:222
@@ -344,7 +379,7 @@ class TileSweep:
                 self._commit_rows(batch[-1][0] - 1 if batch[-1][1] == self.wnm - 1 else batch[0][0] - 2)
         if self.state == "fp16":
             self._commit_rows(self.nrows)
-            self._strips, self._noise_rows = {}, {}
+            self._noise_tiles = {}
             self._exchange(self.cur)
             self.epoch += 1
             return
@@ -400,7 +435,7 @@ class TileSweep:
             raise ValueError(f"epoch {epoch} outside 1..{self.T}")
         d = self.step_dir(out_dir, epoch)
         self.cur.fill_(-1.0)
-        self._pending, self._strips, self._noise_rows = {}, {}, {}
+        self._pending, self._noise_tiles = {}, {}
         for lr in range(self.nrows):
             for c in range(self.wnm):
                 name = tiles.state_tile_name(self.row0 + self.r0 + lr, self.col0 + c)

@@ -140,7 +140,7 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
               init: str = "device", state: str = "fp16", broadcast_weights: bool = True, time_exchange: bool = True,
               prefetch_genes: bool = True, on_step: Optional[Callable] = None,
               after_warmup: Optional[Callable] = None, holder: Optional[dict] = None, share_halo: bool = False,
-              batch_rows: int = 1, cache_level0: bool = False) -> dict:
+              batch_rows: int = 1, cache_level0: bool = False, z_group: Optional[int] = None) -> dict:
     """`main` + `Tester.test` of the reference (test_brn.py:232-295) for this rank: build the rank's TileSweep, run
     `warmup` untimed then `steps` timed diffusion steps (each ending with the halo-strip exchange), and return
     {'sweep': TileSweep, 'dt': seconds of the timed steps on this rank (max over ranks when world > 1), 'step_s': [...],
@@ -160,7 +160,7 @@ def run_sweep(conf, sampler, model, gene_provider: Callable, *, hnm: int, wnm: i
         broadcast_arena(model)
     sw = brain.TileSweep(conf, sampler, model, gene_provider, hst=hst, wst=wst, hnm=hnm, wnm=wnm, total_epochs=total_epochs,
                          total_slc=total_slc, device=dev, rank=rank, world=world, batch_tiles=batch_tiles, init=init, state=state,
-                         share_halo=share_halo, batch_rows=batch_rows, cache_level0=cache_level0)
+                         share_halo=share_halo, batch_rows=batch_rows, cache_level0=cache_level0, z_group=z_group)
     sw.time_exchange = time_exchange
     if holder is not None:
         holder["sweep"] = sw

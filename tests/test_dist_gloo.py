@@ -108,7 +108,7 @@ def test_single_fp16_canvas_state_is_bit_identical(batch_tiles):
     assert sw.nxt is None and sw.cur.dtype == torch.float16
     got = sw.test()
     assert got.dtype == torch.float16 and torch.equal(got.float(), ref)
-    assert not sw._pending and not sw._strips
+    assert not sw._pending and not sw._noise_tiles
 
 
 @pytest.mark.parametrize("world,hnm,state", [(2, HNM, "fp32x2"), (2, HNM, "fp16"), (2, 1, "fp32x2"), (3, 2, "fp16")])

@@ -133,6 +133,11 @@ def test_share_halo_window_is_bit_identical_to_per_tile_calls(dtype, state):
     rows2 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=2, batch_rows=2, share_halo=True, **kw3).test()
     rows3 = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, batch_rows=3, share_halo=True, **kw3).test()
     assert torch.equal(per_tile3, rows2) and torch.equal(per_tile3, rows3)
+    # z_group: a window's images (z-chunks) through the model one at a time -- the workspace of one image, the same bits
+    zg = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=3, batch_rows=3, share_halo=True, z_group=1,
+                   cache_level0=True, **kw3).test()
+    zg_stacked = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, batch_tiles=2, z_group=3, **kw3).test()
+    assert torch.equal(per_tile3, zg) and torch.equal(per_tile3, zg_stacked)
 
 
 @pytest.mark.parametrize("dtype,state", [("f32", "fp32x2"), ("bf16", "fp16")])

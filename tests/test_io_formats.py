@@ -238,7 +238,6 @@ def test_halo_assembly_at_later_steps_vs_reference_pad_im(state):
         for c in range(wnm):
             sw._centre(sw.cur, lr, c).copy_(torch.from_numpy(_ref_state_tile(hst + lr, wst + c, chn).astype(np.float32)))
     sw.epoch = step
-    sw._strips = {}
     sw._exchange(sw.cur)
     for key in [k for k in REF_PAD.files if k.startswith("im/") and k != "im/params"]:
         lr, c = (int(v) for v in key[3:].split("_"))

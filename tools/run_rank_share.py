@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--cols", type=int, default=414)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--batch_tiles", type=int, default=4)
+    ap.add_argument("--batch_rows", type=int, default=1, help="tile rows per shared-halo window")
+    ap.add_argument("--z_group", type=int, default=0, help="images (z-chunks) per model call (0: all 25 of a window at once)")
     ap.add_argument("--deadline_s", type=float, default=1100.0)
     a = ap.parse_args()
     import torch
@@ -36,9 +38,11 @@ def main():
     cfg = PathConfig(gen_type="ddim", compute_dtype=a.dtype)
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
     T = 15
-    genes = consistent_gene_provider(cfg, dev, max_blocks=3 * (a.batch_tiles + 2) + 6, max_tiles=a.batch_tiles + 2)
+    genes = consistent_gene_provider(cfg, dev, max_blocks=(a.batch_rows + 2) * (a.batch_tiles + 2) + 6,
+                                     max_tiles=a.batch_rows * (a.batch_tiles + 2))
     sw = TileSweep(cfg, SpacedDiffusionBeatGans(T, "ddim"), model, genes, hnm=a.rows, wnm=a.cols, total_epochs=T, device=dev,
-                   batch_tiles=a.batch_tiles, init="device", state="fp16", share_halo=True)
+                   batch_tiles=a.batch_tiles, init="device", state="fp16", share_halo=True, batch_rows=a.batch_rows,
+                   z_group=a.z_group or None)
     # a canvas of plausible values in place of the step-0 noise band: rows of N(0, 0.5) clamped to [-1, 1]
     g = torch.Generator(device=dev)
     g.manual_seed(1)
@@ -50,8 +54,8 @@ def main():
     print(f"[rank_share] canvas {tuple(sw.cur.shape)} fp16 = {sw.cur.numel() * 2 / 1e9:.1f} GB, set-up {time.monotonic() - _T0:.0f} s, "
           f"allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr, flush=True)
     # the step, window by window (TileSweep.step), with a progress line per tile row and a wall-clock guard
-    batches = [[(lr, c) for c in range(c0, min(c0 + sw.batch_tiles, sw.wnm))] for lr in range(sw.nrows)
-               for c0 in range(0, sw.wnm, sw.batch_tiles)]
+    batches = [[(lr, c) for lr in range(l0, min(l0 + sw.batch_rows, sw.nrows)) for c in range(c0, min(c0 + sw.batch_tiles, sw.wnm))]
+               for l0 in range(0, sw.nrows, sw.batch_rows) for c0 in range(0, sw.wnm, sw.batch_tiles)]
     t0 = time.perf_counter()
     done_tiles, rows_done = 0, 0
     for batch in batches:
@@ -60,7 +64,7 @@ def main():
         done_tiles += len(batch)
         if batch[-1][1] == sw.wnm - 1:
             torch.cuda.synchronize()
-            rows_done += 1
+            rows_done = batch[-1][0] + 1
             el = time.perf_counter() - t0
             print(f"[rank_share] row {rows_done}/{sw.nrows}: {el:.1f} s, {el / done_tiles * 1e3:.2f} ms per tile, peak "
                   f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", file=sys.stderr, flush=True)
@@ -74,7 +78,7 @@ def main():
     out = {"what": "one diffusion step of one rank's share of the whole-brain sweep (8-GPU row-block partition), measured on one MI355X",
            "rows": a.rows, "cols": a.cols, "tiles_in_share": a.rows * a.cols, "tiles_measured": done_tiles, "full_step": full,
            "dtype": a.dtype, "state": "fp16 single canvas", "canvas_gb": round(sw.cur.numel() * 2 / 1e9, 1),
-           "window_tiles": [1, a.batch_tiles], "share_halo": True,
+           "window_tiles": [a.batch_rows, a.batch_tiles], "z_group": a.z_group or None, "share_halo": True,
            "seconds": round(el, 1), "s_per_tile_step": round(per_tile, 5), "interior_patch_steps_per_s": round(400 / per_tile, 1),
            "step_s_for_the_share": round(per_tile * a.rows * a.cols, 1),
            "whole_brain_T15_8gpu_hours_from_this": round(per_tile * a.rows * a.cols * 15 / 3600, 2),
