@@ -247,7 +247,8 @@ hipError_t launch_pad_patchify(const float* img, float* patches, int b, int C, i
 hipError_t launch_prep_bwd(const float* x, long x_ns, const float* g, long g_ns, const float* mask, long mask_ns, float drop_scale,
                            const float* w, const float* scale, const float* shift, long mod_stride, int per_image, float* dx,
                            long dx_ns, float* dw, float* dscale, float* dshift, int N, int Cb, int C_real, int Z, int S,
-                           hipStream_t s);
+                           float* scratch, hipStream_t s);           // scratch: prep_bwd_scratch_floats(...) floats (two-stage sums)
+size_t prep_bwd_scratch_floats(int N, int Cb, int Z, int S, bool with_mod);
 hipError_t launch_conv_wgrad(const TV& x, const TV& dy, float* dw, int Cin, int Cout, int taps, hipStream_t s);
 hipError_t launch_chan_sum(const TV& x, float* out, int C, hipStream_t s);
 

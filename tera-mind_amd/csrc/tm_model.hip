@@ -2112,8 +2112,10 @@ extern "C" int tm_op_prep_bwd(const void* x_cb8, const void* g_cb8, const void* 
   if (!dwt || !ddw) return fail(TM_ERR_HIP, "device allocation failed");
   TV x = view_cb8(const_cast<void*>(x_cb8), N, C, Z, S, S);
   hipStream_t st = (hipStream_t)stream;
+  float* scratch = tmp.up(nullptr, 0, prep_bwd_scratch_floats(N, Cb, Z, S, scale_host != nullptr));
+  if (!scratch) return fail(TM_ERR_HIP, "device allocation failed");
   hipError_t e = launch_prep_bwd(x.p, x.nstride, (const float*)g_cb8, x.nstride, (const float*)mask_cb8, x.nstride, drop_scale, dwt,
-                                 dsc, dsh, Cp, per_image, (float*)dx_cb8, x.nstride, ddw, ddsc, ddsh, N, Cb, C, Z, S, st);
+                                 dsc, dsh, Cp, per_image, (float*)dx_cb8, x.nstride, ddw, ddsc, ddsh, N, Cb, C, Z, S, scratch, st);
   hipError_t e2 = hipStreamSynchronize(st);
   if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "prep backward: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   std::vector<float> h(Cp);

@@ -23,8 +23,10 @@ namespace tmk {
 //   dw[c] += dn * xh;  dxh = dn * w
 //   dx = rstd * (dxh - xh * mean_c(dxh * xh))
 // lane = voxel, the workgroup's 4 waves split the channel blocks (as prep_kernel); two passes over the channels
-// (first: mean_c(dxh * xh), second: dx); the per-channel sums are reduced over the 64 voxels of a wave in registers
-// (wave_sum) and added to global memory with one float atomic per (wave, channel).
+// (first: mean_c(dxh * xh), second: dx).  The per-channel sums (dw, dscale, dshift) are reduced in TWO STAGES so that the
+// gradients are bitwise reproducible: the 64 voxels of a workgroup in registers (wave_sum), one partial per (workgroup,
+// channel) STORED to a scratch slab, and prep_bwd_reduce_kernel adds the slabs of the workgroups in index order -- no float
+// atomics (their sum depends on arrival order: the last bits changed from run to run).
 // ------------------------------------------------------------------------------------------------------------------
 struct PrepBwdArgs {
   const float* x; long x_ns;            // forward input (pre-norm), CB8 with Cb blocks
@@ -34,8 +36,8 @@ struct PrepBwdArgs {
   const float* w;                       // [Cb*8] norm weight (zero in the pad slots)
   const float* scale; const float* shift; long mod_stride; int per_image;   // [img][..] or null
   float* dx; long dx_ns;
-  float* dw;                            // [Cb*8] accumulated (caller zeroes)
-  float* dscale; float* dshift;         // [img][mod_stride] accumulated, or null
+  float* part_dw;                       // [workgroups][Cb*8] partial sums of this workgroup's 64 voxels
+  float* part_ds; float* part_dh;       // [workgroups][2 (image of lane 0 | the next image)][Cb*8] partial dscale / dshift, or null
   int N, Cb, Z, S; float inv_c;
 };
 
@@ -101,9 +103,9 @@ __global__ __launch_bounds__(256) void prep_bwd_kernel(PrepBwdArgs a) {
       // avoided by summing dn * xh directly
       const float sc = (a.scale && valid) ? a.scale[(long)img * a.mod_stride + c] : 0.f;
       const float dwv = wave_sum(dm[j] * (1.0f + sc) * xh[j]);
-      if (lane == 0 && dwv != 0.f) atomicAdd(a.dw + c, dwv);
+      if (lane == 0) a.part_dw[(long)blockIdx.x * a.Cb * 8 + c] = dwv;
     }
-    if (a.dscale) {
+    if (a.part_ds) {
       // the 64 voxels of a wave may belong to two images only at an image boundary: reduce per image of lane 0 and of
       // the last lane (per_image * vpn >= 64 for every geometry of the model: one patch has >= 128 voxels)
       const int img_lo = __shfl(img, 0, 64);
@@ -113,12 +115,9 @@ __global__ __launch_bounds__(256) void prep_bwd_kernel(PrepBwdArgs a) {
         const float s_lo = wave_sum(img == img_lo ? dm[j] * nn[j] : 0.f), h_lo = wave_sum(img == img_lo ? dm[j] : 0.f);
         const float s_hi = wave_sum(img != img_lo ? dm[j] * nn[j] : 0.f), h_hi = wave_sum(img != img_lo ? dm[j] : 0.f);
         if (lane == 0) {
-          atomicAdd(a.dscale + (long)img_lo * a.mod_stride + c, s_lo);
-          atomicAdd(a.dshift + (long)img_lo * a.mod_stride + c, h_lo);
-          if (s_hi != 0.f || h_hi != 0.f) {
-            atomicAdd(a.dscale + (long)(img_lo + 1) * a.mod_stride + c, s_hi);
-            atomicAdd(a.dshift + (long)(img_lo + 1) * a.mod_stride + c, h_hi);
-          }
+          const long pb = (long)blockIdx.x * 2 * a.Cb * 8;
+          a.part_ds[pb + c] = s_lo; a.part_dh[pb + c] = h_lo;
+          a.part_ds[pb + a.Cb * 8 + c] = s_hi; a.part_dh[pb + a.Cb * 8 + c] = h_hi;
         }
       }
     }
@@ -140,15 +139,63 @@ __global__ __launch_bounds__(256) void prep_bwd_kernel(PrepBwdArgs a) {
   }
 }
 
+// stage 2: out[c] = sum over workgroups (in index order) of part[wg][c]; one thread per channel, eight independent chains
+// combined in a fixed order
+__global__ __launch_bounds__(64) void prep_bwd_reduce_dw_kernel(const float* part, long nwg, int C8, float* dw) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C8) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  long wg = 0;
+  for (; wg + 8 <= nwg; wg += 8)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += part[(wg + u) * C8 + c];
+  for (int u = 0; wg < nwg; ++wg, ++u) acc[u] += part[wg * C8 + c];
+  dw[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+// dscale / dshift[img][c]: the workgroups that hold voxels of image `img` form the index range [img V / 64, ((img + 1) V - 1) / 64]
+// (V = per_image * voxels per patch >= 64): a workgroup whose first voxel belongs to `img` contributes its first slab, the
+// one workgroup that starts in image img - 1 and ends in img its second slab
+__global__ __launch_bounds__(64) void prep_bwd_reduce_mod_kernel(const float* part_ds, const float* part_dh, long nwg, long V, int C8,
+                                                                 long mod_stride, float* dscale, float* dshift) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const long img = blockIdx.y;
+  if (c >= C8) return;
+  const long wa = img * V / 64, wb = ((img + 1) * V - 1) / 64;
+  float s_ = 0.f, h_ = 0.f;
+  for (long wg = wa; wg <= wb && wg < nwg; ++wg) {
+    const long lo = wg * 64 / V;                       // image of the workgroup's first voxel
+    const long pb = (wg * 2 + (lo == img ? 0 : 1)) * C8 + c;
+    s_ += part_ds[pb];
+    h_ += part_dh[pb];
+  }
+  dscale[img * mod_stride + c] = s_;
+  dshift[img * mod_stride + c] = h_;
+}
+
+size_t prep_bwd_scratch_floats(int N, int Cb, int Z, int S, bool with_mod) {
+  const long nwg = ((long)N * Z * S * S + 63) / 64;
+  return (size_t)nwg * Cb * 8 * (with_mod ? 5 : 1);
+}
+
 hipError_t launch_prep_bwd(const float* x, long x_ns, const float* g, long g_ns, const float* mask, long mask_ns, float drop_scale,
                            const float* w, const float* scale, const float* shift, long mod_stride, int per_image, float* dx,
                            long dx_ns, float* dw, float* dscale, float* dshift, int N, int Cb, int C_real, int Z, int S,
-                           hipStream_t s) {
-  if (per_image < 1 || (long)per_image * Z * S * S < 64) return hipErrorInvalidValue;
-  PrepBwdArgs a{x, x_ns, g, g_ns, mask, mask_ns, drop_scale, w, scale, shift, mod_stride, per_image, dx, dx_ns, dw, dscale, dshift,
+                           float* scratch, hipStream_t s) {
+  if (per_image < 1 || (long)per_image * Z * S * S < 64 || !scratch) return hipErrorInvalidValue;
+  const long vox = (long)N * Z * S * S, nwg = (vox + 63) / 64;
+  const int C8 = Cb * 8;
+  float* part_dw = scratch;
+  float* part_ds = scale ? scratch + nwg * C8 : nullptr;
+  float* part_dh = scale ? part_ds + nwg * 2 * C8 : nullptr;
+  PrepBwdArgs a{x, x_ns, g, g_ns, mask, mask_ns, drop_scale, w, scale, shift, mod_stride, per_image, dx, dx_ns, part_dw, part_ds, part_dh,
                 N, Cb, Z, S, 1.0f / (float)C_real};
-  const long vox = (long)N * Z * S * S;
-  hipLaunchKernelGGL(prep_bwd_kernel, dim3((unsigned)((vox + 63) / 64)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(prep_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(prep_bwd_reduce_dw_kernel, dim3((unsigned)((C8 + 63) / 64)), dim3(64), 0, s, part_dw, nwg, C8, dw);
+  if (scale) {
+    const long nimg = (N + per_image - 1) / per_image;
+    hipLaunchKernelGGL(prep_bwd_reduce_mod_kernel, dim3((unsigned)((C8 + 63) / 64), (unsigned)nimg), dim3(64), 0, s, part_ds, part_dh, nwg,
+                       (long)per_image * Z * S * S, C8, mod_stride, dscale, dshift);
+  }
   return hipGetLastError();
 }
 
