@@ -329,6 +329,32 @@ int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx_cb8, int N
 int tm_op_conv_wgrad(const void* x_cb8, const void* dy_cb8, void* dw_host, void* db_host_or_null, int N, int Cin,
                      int Cout, int Z, int S, int ksize, void* stream);
 
+/* ---- training slice, AttnBlock (model/MBAblocks.py:428-514 AttnBlock.forward, :517-601 Attention, :608-614 modulate) -----
+ *   m = adaLN(SiLU(y));  (shift, scale, gate) x (msa, mlp) = m.chunk(6)
+ *   x = x + gate_msa * proj(core(q(modulate(norm1(x))), k(y), v(y)));   x = x + gate_mlp * fc2(GELU(fc1(modulate(norm2(x)))))
+ * Every Linear is a 1x1x1 conv (tm_op_conv_mfma / tm_op_conv_dgrad / tm_op_conv_wgrad with ksize 1); the pieces below are the
+ * rest.  fp32 CB8 device tensors, norm weights HOST.  teramind_amd.training.AttnBlockTrain composes forward and backward;
+ * tests/test_gpu_train.py checks every gradient against the reference module's own autograd (tests/golden/train_attn_ref.npz). */
+
+/* Elementwise on n floats: op 0 o1 = a + b * c | 1 o1 = a * b, o2 = a * c | 2 o1 = gelu_tanh(a) | 3 o1 = a * gelu_tanh'(b) |
+ * 4 o1 = silu(a) | 5 o1 = a * silu'(b) | 6 o1 = a + b. */
+int tm_op_ew(int op, const void* a, const void* b, const void* c, void* o1, void* o2, long n, void* stream);
+
+/* y = RMSNorm_C(x) * norm_w * (1 + scale) + shift with per-voxel scale / shift (CB8 tensors of x's geometry). */
+int tm_op_modnorm(const void* x_cb8, const void* norm_w_host, const void* scale_cb8, const void* shift_cb8, void* y_cb8,
+                  int N, int C, int Z, int S, void* stream);
+
+/* Backward of the above: g = dL/dy -> dx, dscale, dshift (CB8) and dL/dnorm_w [C] (HOST). */
+int tm_op_modnorm_bwd(const void* x_cb8, const void* g_cb8, const void* norm_w_host, const void* scale_cb8, void* dx_cb8,
+                      void* dscale_cb8, void* dshift_cb8, void* dw_host, int N, int C, int Z, int S, void* stream);
+
+/* The attention core (q/k RMSNorm, softmax(q k^T / C) v per 2 x 2 window over (h, w) and all z; one head, n_h = 2):
+ * dout_cb8 == NULL: forward, writes o_cb8.  dout_cb8 != NULL: backward, writes dq / dk / dv (CB8) and the q/k norm weight
+ * gradients [C] (HOST).  Windows of 32, 64 or 128 tokens, C <= 512. */
+int tm_op_window_attn_train(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_host,
+                            const void* kw_host, const void* dout_cb8, void* o_cb8, void* dq_cb8, void* dk_cb8,
+                            void* dv_cb8, void* dqw_host, void* dkw_host, int N, int C, int Z, int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

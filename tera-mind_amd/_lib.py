@@ -79,6 +79,10 @@ SIGNATURES = {
     "tm_op_prep_bwd": (c_int, [c_void_p] * 6 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "tm_op_conv_dgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "tm_op_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "tm_op_ew": (c_int, [c_int] + [c_void_p] * 5 + [C.c_long, c_void_p]),
+    "tm_op_modnorm": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "tm_op_modnorm_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p]),
+    "tm_op_window_attn_train": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_void_p]),
     "tm_op_window_attn": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "tm_op_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
 }

@@ -251,6 +251,13 @@ hipError_t launch_prep_bwd(const float* x, long x_ns, const float* g, long g_ns,
 size_t prep_bwd_scratch_floats(int N, int Cb, int Z, int S, bool with_mod);
 hipError_t launch_conv_wgrad(const TV& x, const TV& dy, float* dw, int Cin, int Cout, int taps, hipStream_t s);
 hipError_t launch_chan_sum(const TV& x, float* out, int C, hipStream_t s);
+// AttnBlock pieces (model/MBAblocks.py:428-614)
+hipError_t launch_ew(int op, const float* a, const float* b, const float* c, float* o1, float* o2, long n, hipStream_t s);
+hipError_t launch_modnorm_bwd(const TV& x, const float* g, const float* w, const float* scale, float* dx, float* dscale, float* dshift,
+                              float* dw, int C_real, float* scratch, hipStream_t s);   // scratch: ceil(voxels / 64) * Cb * 8 floats
+hipError_t launch_attn_train(const TV& q, const TV& k, const TV& v, const float* qw, const float* kw, const float* dout, float* o,
+                             float* dq, float* dk, float* dv, float* dqw, float* dkw, float* scratch, bool bwd,
+                             hipStream_t s);                                            // scratch (bwd): 2 * N * 4 * Cb * 8 floats
 
 // ---- tile I/O (tm_io.hip) --------------------------------------------------------------
 int io_fail(int code, const char* msg);     // sets the tm_last_error() text, returns code

@@ -2135,6 +2135,100 @@ extern "C" int tm_op_prep_bwd(const void* x_cb8, const void* g_cb8, const void* 
 
 // dX of Conv3d(k = 3x3x3 pad 1 | 1x1x1), stride 1: the forward MFMA conv of dY with the kernel flipped in z, y, x and
 // cin <-> cout transposed (w_host [Cout][Cin][taps] as in the reference state_dict)
+// ---- AttnBlock training pieces (teramind_amd.training.AttnBlockTrain composes them) ----
+extern "C" int tm_op_ew(int op, const void* a, const void* b, const void* c, void* o1, void* o2, long n, void* stream) {
+  if (op < 0 || op > 6 || !a || !o1 || n < 0) return fail(TM_ERR_ARG, "bad argument");
+  if ((op == 0 || op == 1) && (!b || !c)) return fail(TM_ERR_ARG, "op %d needs b and c", op);
+  if ((op == 3 || op == 5 || op == 6) && !b) return fail(TM_ERR_ARG, "op %d needs b", op);
+  if (op == 1 && !o2) return fail(TM_ERR_ARG, "op 1 needs two outputs");
+  hipError_t e = launch_ew(op, (const float*)a, (const float*)b, (const float*)c, (float*)o1, (float*)o2, n, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "elementwise op: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
+extern "C" int tm_op_modnorm(const void* x_cb8, const void* norm_w_host, const void* scale_cb8, const void* shift_cb8, void* y_cb8, int N,
+                             int C, int Z, int S, void* stream) {
+  if (!x_cb8 || !norm_w_host || !scale_cb8 || !shift_cb8 || !y_cb8) return fail(TM_ERR_ARG, "bad argument");
+  const int Cb = (C + 7) / 8, Cp = Cb * 8;
+  DevTmp tmp;
+  const std::vector<float> wp = pad_rows((const float*)norm_w_host, 1, C, Cp);
+  const float* dw = tmp.up(wp.data(), Cp);
+  if (!dw) return fail(TM_ERR_HIP, "device allocation failed");
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, C, Z, S, S), y = view_cb8(y_cb8, N, C, Z, S, S);
+  PrepLaunch P;
+  P.nsrc = 1;
+  P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+  P.N = N; P.Z = Z; P.S = S; P.norm_w = dw; P.inv_c = 1.0f / (float)C; P.act = 0;
+  P.mod = MOD_VOXEL; P.mod_scale = (const float*)scale_cb8; P.mod_shift = (const float*)shift_cb8; P.mod_stride = x.nstride;
+  P.out = y.p; P.out_nstride = y.nstride;
+  hipError_t e = launch_prep(P, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "modulate(norm): %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
+extern "C" int tm_op_modnorm_bwd(const void* x_cb8, const void* g_cb8, const void* norm_w_host, const void* scale_cb8, void* dx_cb8,
+                                 void* dscale_cb8, void* dshift_cb8, void* dw_host, int N, int C, int Z, int S, void* stream) {
+  if (!x_cb8 || !g_cb8 || !norm_w_host || !scale_cb8 || !dx_cb8 || !dscale_cb8 || !dshift_cb8 || !dw_host)
+    return fail(TM_ERR_ARG, "bad argument");
+  const int Cb = (C + 7) / 8, Cp = Cb * 8;
+  DevTmp tmp;
+  const std::vector<float> wp = pad_rows((const float*)norm_w_host, 1, C, Cp);
+  const float* dwt = tmp.up(wp.data(), Cp);
+  float* ddw = tmp.up(nullptr, 0, Cp);
+  const long vox = (long)N * Z * S * S;
+  float* scratch = tmp.up(nullptr, 0, (size_t)((vox + 63) / 64) * Cp);
+  if (!dwt || !ddw || !scratch) return fail(TM_ERR_HIP, "device allocation failed");
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, C, Z, S, S);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = launch_modnorm_bwd(x, (const float*)g_cb8, dwt, (const float*)scale_cb8, (float*)dx_cb8, (float*)dscale_cb8,
+                                    (float*)dshift_cb8, ddw, C, scratch, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "modulate(norm) backward: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  std::vector<float> h(Cp);
+  HIP_TRY(hipMemcpy(h.data(), ddw, Cp * sizeof(float), hipMemcpyDeviceToHost));
+  memcpy(dw_host, h.data(), C * sizeof(float));
+  return TM_OK;
+}
+
+extern "C" int tm_op_window_attn_train(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_host, const void* kw_host,
+                                       const void* dout_cb8, void* o_cb8, void* dq_cb8, void* dk_cb8, void* dv_cb8, void* dqw_host,
+                                       void* dkw_host, int N, int C, int Z, int S, void* stream) {
+  const bool bwd = dout_cb8 != nullptr;
+  if (!q_cb8 || !k_cb8 || !v_cb8 || !qw_host || !kw_host) return fail(TM_ERR_ARG, "bad argument");
+  if (bwd ? (!dq_cb8 || !dk_cb8 || !dv_cb8 || !dqw_host || !dkw_host) : !o_cb8) return fail(TM_ERR_ARG, "missing output");
+  const int T = Z * (S / 2) * (S / 2);
+  if ((S & 1) || (T != 32 && T != 64 && T != 128) || C > 512 || C < 1)
+    return fail(TM_ERR_ARG, "window of %d tokens / C = %d: the training attention core takes 32, 64 or 128 tokens and C <= 512", T, C);
+  const int Cb = (C + 7) / 8, Cp = Cb * 8;
+  DevTmp tmp;
+  const std::vector<float> qp = pad_rows((const float*)qw_host, 1, C, Cp), kp = pad_rows((const float*)kw_host, 1, C, Cp);
+  const float *dqw_in = tmp.up(qp.data(), Cp), *dkw_in = tmp.up(kp.data(), Cp);
+  float *gq = nullptr, *gk = nullptr, *scratch = nullptr;
+  if (bwd) {
+    gq = tmp.up(nullptr, 0, Cp); gk = tmp.up(nullptr, 0, Cp);
+    scratch = tmp.up(nullptr, 0, (size_t)2 * N * 4 * Cp);
+    if (!gq || !gk || !scratch) return fail(TM_ERR_HIP, "device allocation failed");
+  }
+  if (!dqw_in || !dkw_in) return fail(TM_ERR_HIP, "device allocation failed");
+  TV q = view_cb8(const_cast<void*>(q_cb8), N, C, Z, S, S), k = view_cb8(const_cast<void*>(k_cb8), N, C, Z, S, S),
+     v = view_cb8(const_cast<void*>(v_cb8), N, C, Z, S, S);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = launch_attn_train(q, k, v, dqw_in, dkw_in, (const float*)dout_cb8, (float*)o_cb8, (float*)dq_cb8, (float*)dk_cb8,
+                                   (float*)dv_cb8, gq, gk, scratch, bwd, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "window attention (training): %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  if (bwd) {
+    std::vector<float> h(Cp);
+    HIP_TRY(hipMemcpy(h.data(), gq, Cp * sizeof(float), hipMemcpyDeviceToHost));
+    memcpy(dqw_host, h.data(), C * sizeof(float));
+    HIP_TRY(hipMemcpy(h.data(), gk, Cp * sizeof(float), hipMemcpyDeviceToHost));
+    memcpy(dkw_host, h.data(), C * sizeof(float));
+  }
+  return TM_OK;
+}
+
 extern "C" int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx_cb8, int N, int Cin, int Cout, int Z, int S,
                                 int ksize, void* stream) {
   if (!dy_cb8 || !w_host || !dx_cb8 || (ksize != 1 && ksize != 3)) return fail(TM_ERR_ARG, "bad argument");

@@ -308,4 +308,302 @@ hipError_t launch_chan_sum(const TV& x, float* out, int C, hipStream_t s) {
   return hipGetLastError();
 }
 
+
+// ==================================================================================================================
+// AttnBlock training slice (model/MBAblocks.py:428-514,517-601,608-614): elementwise pieces, the per-voxel adaLN
+// modulate(norm(x)) backward, and the windowed cross-attention core forward + backward.  fp32, functional (not tuned):
+// every Linear of the block is a 1x1x1 conv and runs, forward and backward, on the conv kernels above.
+// ==================================================================================================================
+
+// ---- elementwise ops on flat fp32 buffers (CB8 tensors of one geometry) ----
+//   0 GATE_ADD  o1 = a + b * c          x + gate * value                         (MBAblocks.py:488-489)
+//   1 MUL2      o1 = a * b, o2 = a * c  d(value) = d * gate, d(gate) = d * value
+//   2 GELU      o1 = gelu_tanh(a)       timm Mlp act (approx_gelu, MBAblocks.py:18)
+//   3 GELU_BWD  o1 = a * gelu_tanh'(b)
+//   4 SILU      o1 = silu(a)            adaLN_modulation[0] (MBAblocks.py:463)
+//   5 SILU_BWD  o1 = a * silu'(b)
+//   6 ADD       o1 = a + b
+__global__ __launch_bounds__(256) void ew_kernel(int op, const float* a, const float* b, const float* c, float* o1, float* o2, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float av = a[i];
+    switch (op) {
+      case 0: o1[i] = av + b[i] * c[i]; break;
+      case 1: o1[i] = av * b[i]; o2[i] = av * c[i]; break;
+      case 2: o1[i] = gelu_tanh_f(av); break;
+      case 3: {
+        const float x = b[i], kB = 0.7978845608028654f, kK = 0.044715f;
+        const float u = kB * (x + kK * x * x * x), th = tanhf(u);
+        o1[i] = av * (0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * kB * (1.0f + 3.0f * kK * x * x));
+        break;
+      }
+      case 4: o1[i] = silu_f(av); break;
+      case 5: { const float x = b[i], sg = 1.0f / (1.0f + expf(-x)); o1[i] = av * sg * (1.0f + x * (1.0f - sg)); break; }
+      default: o1[i] = av + b[i]; break;
+    }
+  }
+}
+hipError_t launch_ew(int op, const float* a, const float* b, const float* c, float* o1, float* o2, long n, hipStream_t s) {
+  if (op < 0 || op > 6 || !a || !o1 || n < 0) return hipErrorInvalidValue;
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)g), dim3(256), 0, s, op, a, b, c, o1, o2, n);
+  return hipGetLastError();
+}
+
+// ---- modulate(norm, x, shift, scale) backward with PER-VOXEL shift / scale (MBAblocks.py:608-614) ----
+//   forward  y = RMSNorm_C(x) * w * (1 + scale) + shift         scale, shift: CB8 tensors of x's geometry
+//   backward dscale = g * n (n = xh * w), dshift = g, dn = g * (1 + scale), dw[c] += sum_v dn * xh,
+//            dx = rstd * (dn * w - xh * mean_c(dn * w * xh))
+// Same structure as prep_bwd_kernel: lane = voxel, four waves split the channel blocks; dw through the two-stage reduction.
+struct ModNormBwdArgs {
+  const float* x; const float* g; const float* w; const float* scale;
+  float* dx; float* dscale; float* dshift; float* part_dw;
+  long ns; int N, Cb, Z, S; float inv_c;
+};
+__global__ __launch_bounds__(256) void modnorm_bwd_kernel(ModNormBwdArgs a) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long vpn = (long)a.Z * a.S * a.S;
+  const long vidx = (long)blockIdx.x * 64 + lane;
+  const bool valid = vidx < vpn * a.N;
+  const int n = valid ? (int)(vidx / vpn) : 0;
+  const long off = valid ? (vidx - (long)n * vpn) * 8 : 0;
+  const long plane = vpn * 8;
+  float ssq = 0.f;
+  if (valid)
+    for (int cb = wv; cb < a.Cb; cb += 4) {
+      const float* p = a.x + (long)n * a.ns + (long)cb * plane + off;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssq += p[j] * p[j];
+    }
+  red[wv][lane] = ssq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * a.inv_c + TM_EPS);
+  __syncthreads();
+  float dot = 0.f;
+  for (int cb = wv; cb < a.Cb; cb += 4) {
+    const long o = (long)n * a.ns + (long)cb * plane + off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      float xh = 0.f, dn = 0.f;
+      if (valid) { xh = a.x[o + j] * rstd; dn = a.g[o + j] * (1.0f + a.scale[o + j]); }
+      dot += dn * a.w[c] * xh;
+      const float dwv = wave_sum(dn * xh);
+      if (lane == 0) a.part_dw[(long)blockIdx.x * a.Cb * 8 + c] = dwv;
+    }
+  }
+  red[wv][lane] = dot;
+  __syncthreads();
+  const float mean_dot = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * a.inv_c;
+  if (!valid) return;
+  for (int cb = wv; cb < a.Cb; cb += 4) {
+    const long o = (long)n * a.ns + (long)cb * plane + off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      const float xh = a.x[o + j] * rstd, gv = a.g[o + j];
+      a.dscale[o + j] = gv * xh * a.w[c];
+      a.dshift[o + j] = gv;
+      a.dx[o + j] = rstd * (gv * (1.0f + a.scale[o + j]) * a.w[c] - xh * mean_dot);
+    }
+  }
+}
+hipError_t launch_modnorm_bwd(const TV& x, const float* g, const float* w, const float* scale, float* dx, float* dscale, float* dshift,
+                              float* dw, int C_real, float* scratch, hipStream_t s) {
+  const long vox = (long)x.N * x.Z * x.H * x.W, nwg = (vox + 63) / 64;
+  ModNormBwdArgs a{x.p, g, w, scale, dx, dscale, dshift, scratch, x.nstride, x.N, x.Cb, x.Z, x.H, 1.0f / (float)C_real};
+  hipLaunchKernelGGL(modnorm_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(prep_bwd_reduce_dw_kernel, dim3((unsigned)((x.Cb * 8 + 63) / 64)), dim3(64), 0, s, scratch, nwg, x.Cb * 8, dw);
+  return hipGetLastError();
+}
+
+// ---- windowed cross-attention core (MBAblocks.py:551-601, n_h = 2, one head): forward and backward ----
+//   qh = RMSNorm_C(q) * qw, kh = RMSNorm_C(k) * kw;  S = qh kh^T / C;  P = softmax_j S;  o = P v        per window of
+//   T = Z (S/2)^2 tokens (2 x 2 windows over (h, w), all z).  One workgroup per (patch, window), T <= 128, C <= 512.
+//   Backward recomputes P:  dv = P^T do;  dP = do v^T;  dS = P (dP - rowsum(dP P)) / C;  dqh = dS kh;  dkh = dS^T qh;
+//   RMSNorm backward per token (g = dqh * qw: dq = r g - q r^3 mean_c(g q));  d(qw)[c] = sum_tokens dqh q r -- per-workgroup
+//   partials, reduced in index order by prep_bwd_reduce_dw_kernel.
+struct AttnTrainArgs {
+  const float *q, *k, *v, *qw, *kw, *dout;
+  float *o;                            // forward output (BWD == false)
+  float *dq, *dk, *dv, *part_qw, *part_kw;
+  long ns; int C, Cb, Z, S, T;
+};
+constexpr int AT_CH = 16;              // channels per staged chunk
+template <bool BWD>
+__global__ __launch_bounds__(256) void attn_train_kernel(AttnTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = a.T, C = a.C, tid = threadIdx.x;
+  float* Pm = sm;                                  // [T][T]
+  float* Dm = Pm + (BWD ? T * T : 0);              // [T][T] (backward)
+  float* A = Dm + T * T;                           // [T][AT_CH] staged operand (row scaled)
+  float* B = A + T * AT_CH;                        // [T][AT_CH]
+  float* rq = B + T * AT_CH;                       // [T]
+  float* rk = rq + T;
+  float* rowdot = rk + T;                          // [T]
+  float* pdot = rowdot + T;                        // [T][8] partial dots
+  int* tokoff = (int*)(pdot + T * 8);              // [T]
+  const int S = a.S, hs = S / 2;
+  const int n = blockIdx.x >> 2, win = blockIdx.x & 3, wy = win >> 1, wx = win & 1;
+  const long plane = (long)a.Z * S * S * 8;
+  const long nb = (long)n * a.ns;
+  if (tid < T) {
+    const int z = tid / (hs * hs), r = tid - z * hs * hs, yl = r / hs, xl = r - yl * hs;
+    tokoff[tid] = ((z * S + wy * hs + yl) * S + wx * hs + xl) * 8;
+  }
+  __syncthreads();
+  auto at = [&](const float* base, int t, int c) -> float { return base[nb + (long)(c >> 3) * plane + tokoff[t] + (c & 7)]; };
+  auto put = [&](float* base, int t, int c, float v) { base[nb + (long)(c >> 3) * plane + tokoff[t] + (c & 7)] = v; };
+  for (int t = tid; t < 2 * T; t += 256) {
+    const float* src = t < T ? a.q : a.k;
+    const int tt = t < T ? t : t - T;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) { const float v = at(src, tt, c); ss += v * v; }
+    (t < T ? rq : rk)[tt] = 1.0f / sqrtf(ss / (float)C + TM_EPS);
+  }
+  __syncthreads();
+  // stage rows [T][AT_CH] of `src` for channels c0 .. c0 + AT_CH: value * rowscale[t] * colscale[c] (either may be null)
+  auto stage = [&](float* dst, const float* src, int c0, const float* rs, const float* cs) {
+    for (int e = tid; e < T * AT_CH; e += 256) {
+      const int t = e / AT_CH, cc = e - t * AT_CH, c = c0 + cc;
+      float v = 0.f;
+      if (c < C) { v = at(src, t, c); if (rs) v *= rs[t]; if (cs) v *= cs[c]; }
+      dst[e] = v;
+    }
+  };
+  // M[i][j] = sum_c X[i][c] Y[j][c] over all channels (X, Y staged chunk by chunk); thread (ti, tj) owns a TT x TT tile
+  const int TT = T / 16, ti = tid >> 4, tj = tid & 15;
+  auto gemm_nt = [&](float* M, const float* X, const float* xr, const float* xc, const float* Y, const float* yr, const float* yc, float mul) {
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += AT_CH) {
+      __syncthreads();
+      stage(A, X, c0, xr, xc);
+      stage(B, Y, c0, yr, yc);
+      __syncthreads();
+      for (int cc = 0; cc < AT_CH; ++cc)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < TT) {
+            const float xv = A[(ti * TT + i) * AT_CH + cc];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < TT) acc[i][j] = fmaf(xv, B[(tj * TT + j) * AT_CH + cc], acc[i][j]);
+          }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i < TT && j < TT) M[(ti * TT + i) * T + tj * TT + j] = acc[i][j] * mul;
+    __syncthreads();
+  };
+  // P = softmax(qh kh^T / C)
+  gemm_nt(Pm, a.q, rq, a.qw, a.k, rk, a.kw, 1.0f / (float)C);
+  if (tid < T) {
+    float m = -INFINITY;
+    for (int j = 0; j < T; ++j) m = fmaxf(m, Pm[tid * T + j]);
+    float sum = 0.f;
+    for (int j = 0; j < T; ++j) { const float e = expf(Pm[tid * T + j] - m); Pm[tid * T + j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < T; ++j) Pm[tid * T + j] *= inv;
+  }
+  __syncthreads();
+  // out[r][c] = sum_k M(r, k) * Y[k][c] for every channel, M(r, k) = trans ? Mat[k][r] : Mat[r][k]; thread -> (row, channel subset)
+  const int NTR = 256 / T, row = tid % T, sub = tid / T, cps = AT_CH / NTR;       // NTR in {2, 4, 8}: cps in {8, 4, 2}
+  auto matmul_out = [&](const float* Mat, bool trans, const float* Y, const float* yr, const float* yc, float* out, const float* rdot_src,
+                        const float* rdot_w, float* dotacc) {
+    for (int c0 = 0; c0 < C; c0 += AT_CH) {
+      __syncthreads();
+      stage(B, Y, c0, yr, yc);
+      __syncthreads();
+      for (int u = 0; u < cps; ++u) {
+        const int cc = sub * cps + u, c = c0 + cc;
+        if (c >= C) continue;
+        float s_ = 0.f;
+        for (int k = 0; k < T; ++k) s_ = fmaf(trans ? Mat[k * T + row] : Mat[row * T + k], B[k * AT_CH + cc], s_);
+        put(out, row, c, s_);
+        if (dotacc) *dotacc += s_ * rdot_w[c] * at(rdot_src, row, c);
+      }
+    }
+    __syncthreads();
+  };
+  if (!BWD) {
+    matmul_out(Pm, false, a.v, nullptr, nullptr, a.o, nullptr, nullptr, nullptr);
+    return;
+  }
+  // dv = P^T dout
+  matmul_out(Pm, true, a.dout, nullptr, nullptr, a.dv, nullptr, nullptr, nullptr);
+  // dP = dout v^T ; dS = P (dP - rowsum(dP P)) / C
+  gemm_nt(Dm, a.dout, nullptr, nullptr, a.v, nullptr, nullptr, 1.0f);
+  if (tid < T) {
+    float rd = 0.f;
+    for (int j = 0; j < T; ++j) rd += Dm[tid * T + j] * Pm[tid * T + j];
+    rowdot[tid] = rd;
+  }
+  __syncthreads();
+  for (int e = tid; e < T * T; e += 256) { const int i = e / T; Dm[e] = Pm[e] * (Dm[e] - rowdot[i]) / (float)C; }
+  __syncthreads();
+  // dqh = dS kh (stored in dq for now), partial dots of g q with g = dqh * qw; then the RMSNorm backward in place
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* Xsrc = pass == 0 ? a.q : a.k;           // the tensor being differentiated
+    const float* Ysrc = pass == 0 ? a.k : a.q;           // the other operand (normalised)
+    const float* xr = pass == 0 ? rq : rk; const float* yr = pass == 0 ? rk : rq;
+    const float* xw = pass == 0 ? a.qw : a.kw; const float* yw = pass == 0 ? a.kw : a.qw;
+    float* dX = pass == 0 ? a.dq : a.dk;
+    float* part = pass == 0 ? a.part_qw : a.part_kw;
+    float mydot = 0.f;
+    matmul_out(Dm, pass == 1, Ysrc, yr, yw, dX, Xsrc, xw, &mydot);
+    pdot[row * 8 + sub] = mydot;
+    __syncthreads();
+    if (tid < T) { float d = 0.f; for (int u = 0; u < NTR; ++u) d += pdot[tid * 8 + u]; rowdot[tid] = d / (float)C; }
+    __syncthreads();
+    // per-channel partial of d(norm weight): sum over the window's tokens of dXh[t][c] * x[t][c] * r[t]   (dXh still in dX)
+    for (int c = tid; c < a.Cb * 8; c += 256) {
+      float s_ = 0.f;
+      if (c < C) for (int t = 0; t < T; ++t) s_ += at(dX, t, c) * at(Xsrc, t, c) * xr[t];
+      part[(long)blockIdx.x * a.Cb * 8 + c] = s_;
+    }
+    __syncthreads();
+    // dx = r g - x r^3 mean_c(g x),  g = dXh * w
+    for (int e = tid; e < T * C; e += 256) {
+      const int t = e / C, c = e - t * C;
+      const float r = xr[t], xv = at(Xsrc, t, c);
+      put(dX, t, c, r * at(dX, t, c) * xw[c] - xv * r * r * r * rowdot[t]);
+    }
+    __syncthreads();
+  }
+}
+size_t attn_train_lds_bytes(int T, bool bwd) { return (size_t)((bwd ? 2 : 1) * T * T + 2 * T * AT_CH + 3 * T + T * 8 + T) * 4; }
+hipError_t launch_attn_train(const TV& q, const TV& k, const TV& v, const float* qw, const float* kw, const float* dout, float* o,
+                             float* dq, float* dk, float* dv, float* dqw, float* dkw, float* scratch, bool bwd, hipStream_t s) {
+  const int S = q.H, T = q.Z * (S / 2) * (S / 2);
+  if (q.H != q.W || (S & 1) || (T != 32 && T != 64 && T != 128) || q.C > 512 || k.nstride != q.nstride || v.nstride != q.nstride)
+    return hipErrorInvalidValue;
+  const long nwg = (long)q.N * 4;
+  AttnTrainArgs a{q.p, k.p, v.p, qw, kw, dout, o, dq, dk, dv, scratch, scratch ? scratch + nwg * q.Cb * 8 : nullptr, q.nstride, q.C, q.Cb,
+                  q.Z, S, T};
+  const size_t lds = attn_train_lds_bytes(T, bwd);
+  static DevOnce attr_done;
+  if (attr_done.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_train_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_train_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done.mark();
+  }
+  if (bwd) {
+    hipLaunchKernelGGL(attn_train_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(prep_bwd_reduce_dw_kernel, dim3((unsigned)((q.Cb * 8 + 63) / 64)), dim3(64), 0, s, a.part_qw, nwg, q.Cb * 8, dqw);
+    hipLaunchKernelGGL(prep_bwd_reduce_dw_kernel, dim3((unsigned)((q.Cb * 8 + 63) / 64)), dim3(64), 0, s, a.part_kw, nwg, q.Cb * 8, dkw);
+  } else {
+    hipLaunchKernelGGL(attn_train_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, s, a);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace tmk

@@ -142,3 +142,145 @@ class ResBlockTrain:
         else:
             dx = dx + g
         return _ncdhw(dx, Cin), dscale, dshift, grads
+
+
+class AttnBlockTrain:
+    """One AttnBlock with gene cross-attention (model/MBAblocks.py:428-514: gene_trans=True, cond given, num_heads 1, n_h 2)
+    forward and backward on the HIP kernels.  Parameters as a dict with the reference's key suffixes: norm1.weight,
+    norm2.weight, attn.{q,k,v,proj}.{weight,bias}, attn.{q_norm,k_norm}.weight, mlp.{fc1,fc2}.{weight,bias},
+    adaLN_modulation.1.{weight,bias}.  forward(x [N,C,Z,S,S], cond [N,G,Z,S,S]) -> out; backward(dout) -> (dx, dcond, grads).
+
+        sc = SiLU(cond);  m = Linear_{G -> 7C}(sc);  shift_msa, scale_msa, gate_msa, crss, shift_mlp, scale_mlp, gate_mlp = m.chunk(7)
+        x1 = x + gate_msa * proj(core(q(modulate(norm1, x, shift_msa, scale_msa)), k(crss), v(crss)))
+        out = x1 + gate_mlp * fc2(GELU_tanh(fc1(modulate(norm2, x1, shift_mlp, scale_mlp))))
+
+    Every Linear runs as a 1x1x1 conv on the MFMA conv kernel (forward, data gradient with transposed weights) and
+    conv_wgrad_kernel; modulate(norm) on prep_kernel / modnorm_bwd_kernel; the windowed attention core on attn_train_kernel;
+    the gates and activations on ew_kernel (csrc/tm_train.hip).  Channel chunks / concatenations of the CB8 tensors are torch
+    slices on the device (C a multiple of 8)."""
+
+    LIN = ("attn.q", "attn.k", "attn.v", "attn.proj", "mlp.fc1", "mlp.fc2", "adaLN_modulation.1")
+
+    def __init__(self, params: Dict[str, torch.Tensor], device="cuda:0"):
+        self.p = {k: _host(v) for k, v in params.items()}
+        self.dev = torch.device(device)
+        self.C = self.p["attn.q.weight"].shape[0]
+        self.G = self.p["adaLN_modulation.1.weight"].shape[1]
+        self.hid = self.p["mlp.fc1.weight"].shape[0]
+        if self.C % 8:
+            raise ValueError("AttnBlockTrain: hidden size must be a multiple of 8")
+        self._saved = None
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def _geo(self):
+        return self._saved["shape"]
+
+    def _lin(self, x_cb, name, cin, cout):
+        N, Z, S = self._geo()
+        y = torch.zeros((N, (cout + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.lib().tm_op_conv_mfma(_lib.ptr(x_cb), _hp(self.p[name + ".weight"]), _hp(self.p[name + ".bias"]), _lib.ptr(y), N, cin,
+                                              cout, Z, S, 1, 0, 0, 0, _lib.current_stream_ptr()), "tm_op_conv_mfma")
+        return y
+
+    def _lin_bwd(self, x_cb, dy_cb, name, cin, cout, grads, need_dx=True):
+        N, Z, S = self._geo()
+        dw = torch.empty((cout, cin), dtype=torch.float32)
+        db = torch.empty((cout,), dtype=torch.float32)
+        _lib.check(_lib.lib().tm_op_conv_wgrad(_lib.ptr(x_cb), _lib.ptr(dy_cb), _hp(dw), _hp(db), N, cin, cout, Z, S, 1,
+                                               _lib.current_stream_ptr()), "tm_op_conv_wgrad")
+        grads[name + ".weight"], grads[name + ".bias"] = dw, db
+        if not need_dx:
+            return None
+        dx = torch.zeros((N, (cin + 7) // 8, Z, S, S, 8), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.lib().tm_op_conv_dgrad(_lib.ptr(dy_cb), _hp(self.p[name + ".weight"]), _lib.ptr(dx), N, cin, cout, Z, S, 1,
+                                               _lib.current_stream_ptr()), "tm_op_conv_dgrad")
+        return dx
+
+    def _ew(self, op, a, b=None, c=None, two=False):
+        o1 = torch.empty_like(a)
+        o2 = torch.empty_like(a) if two else None
+        _lib.check(_lib.lib().tm_op_ew(op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(o1), _lib.ptr(o2), a.numel(),
+                                       _lib.current_stream_ptr()), "tm_op_ew")
+        return (o1, o2) if two else o1
+
+    def _modnorm(self, x_cb, w, scale, shift):
+        N, Z, S = self._geo()
+        y = torch.empty_like(x_cb)
+        _lib.check(_lib.lib().tm_op_modnorm(_lib.ptr(x_cb), _hp(w), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), N, self.C, Z, S,
+                                            _lib.current_stream_ptr()), "tm_op_modnorm")
+        return y
+
+    def _modnorm_bwd(self, x_cb, g_cb, w, scale):
+        N, Z, S = self._geo()
+        dx, dsc, dsh = torch.empty_like(x_cb), torch.empty_like(x_cb), torch.empty_like(x_cb)
+        dw = torch.empty((self.C,), dtype=torch.float32)
+        _lib.check(_lib.lib().tm_op_modnorm_bwd(_lib.ptr(x_cb), _lib.ptr(g_cb), _hp(w), _lib.ptr(scale), _lib.ptr(dx), _lib.ptr(dsc),
+                                                _lib.ptr(dsh), _hp(dw), N, self.C, Z, S, _lib.current_stream_ptr()), "tm_op_modnorm_bwd")
+        return dx, dsc, dsh, dw
+
+    def _core(self, q, k, v, dout=None):
+        N, Z, S = self._geo()
+        qw, kw = self.p["attn.q_norm.weight"], self.p["attn.k_norm.weight"]
+        if dout is None:
+            o = torch.zeros_like(q)
+            _lib.check(_lib.lib().tm_op_window_attn_train(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _hp(qw), _hp(kw), None, _lib.ptr(o), None,
+                                                          None, None, None, None, N, self.C, Z, S, _lib.current_stream_ptr()),
+                       "tm_op_window_attn_train")
+            return o
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+        dqw, dkw = torch.empty((self.C,), dtype=torch.float32), torch.empty((self.C,), dtype=torch.float32)
+        _lib.check(_lib.lib().tm_op_window_attn_train(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _hp(qw), _hp(kw), _lib.ptr(dout), None,
+                                                      _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _hp(dqw), _hp(dkw), N, self.C, Z, S,
+                                                      _lib.current_stream_ptr()), "tm_op_window_attn_train")
+        return dq, dk, dv, dqw, dkw
+
+    # -- forward / backward ---------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        N, Cc, Z, S, _ = x.shape
+        assert Cc == self.C and cond.shape[1] == self.G and cond.shape[0] == N and tuple(cond.shape[2:]) == tuple(x.shape[2:])
+        P, Cb = self.p, self.C // 8
+        self._saved = dict(shape=(N, Z, S))
+        x_cb, cond_cb = _cb8(x.to(self.dev).float()), _cb8(cond.to(self.dev).float())
+        sc = self._ew(4, cond_cb)
+        m = self._lin(sc, "adaLN_modulation.1", self.G, 7 * self.C)
+        shift_msa, scale_msa, gate_msa, crss, shift_mlp, scale_mlp, gate_mlp = (m[:, i * Cb:(i + 1) * Cb].contiguous() for i in range(7))
+        n1 = self._modnorm(x_cb, P["norm1.weight"], scale_msa, shift_msa)
+        q = self._lin(n1, "attn.q", self.C, self.C)
+        k = self._lin(crss, "attn.k", self.C, self.C)
+        v = self._lin(crss, "attn.v", self.C, self.C)
+        o = self._core(q, k, v)
+        pr = self._lin(o, "attn.proj", self.C, self.C)
+        x1 = self._ew(0, x_cb, gate_msa, pr)
+        n2 = self._modnorm(x1, P["norm2.weight"], scale_mlp, shift_mlp)
+        h = self._lin(n2, "mlp.fc1", self.C, self.hid)
+        a = self._ew(2, h)
+        f = self._lin(a, "mlp.fc2", self.hid, self.C)
+        out = self._ew(0, x1, gate_mlp, f)
+        self._saved.update(x_cb=x_cb, cond_cb=cond_cb, sc=sc, scale_msa=scale_msa, gate_msa=gate_msa, crss=crss, scale_mlp=scale_mlp,
+                           gate_mlp=gate_mlp, n1=n1, q=q, k=k, v=v, o=o, pr=pr, x1=x1, n2=n2, h=h, a=a, f=f)
+        return _ncdhw(out, self.C)
+
+    def backward(self, dout: torch.Tensor):
+        s, P = self._saved, self.p
+        C_, G, hid = self.C, self.G, self.hid
+        grads: Dict[str, torch.Tensor] = {}
+        g = _cb8(dout.to(self.dev).float())
+        # out = x1 + gate_mlp * f
+        d_f, d_gate_mlp = self._ew(1, g, s["gate_mlp"], s["f"], two=True)
+        d_a = self._lin_bwd(s["a"], d_f, "mlp.fc2", hid, C_, grads)
+        d_h = self._ew(3, d_a, s["h"])
+        d_n2 = self._lin_bwd(s["n2"], d_h, "mlp.fc1", C_, hid, grads)
+        dx1b, dscale_mlp, dshift_mlp, grads["norm2.weight"] = self._modnorm_bwd(s["x1"], d_n2, P["norm2.weight"], s["scale_mlp"])
+        dx1 = self._ew(6, g, dx1b)
+        # x1 = x + gate_msa * pr
+        d_pr, d_gate_msa = self._ew(1, dx1, s["gate_msa"], s["pr"], two=True)
+        d_o = self._lin_bwd(s["o"], d_pr, "attn.proj", C_, C_, grads)
+        dq, dk, dv, grads["attn.q_norm.weight"], grads["attn.k_norm.weight"] = self._core(s["q"], s["k"], s["v"], d_o)
+        d_n1 = self._lin_bwd(s["n1"], dq, "attn.q", C_, C_, grads)
+        d_crss = self._ew(6, self._lin_bwd(s["crss"], dk, "attn.k", C_, C_, grads), self._lin_bwd(s["crss"], dv, "attn.v", C_, C_, grads))
+        dxa, dscale_msa, dshift_msa, grads["norm1.weight"] = self._modnorm_bwd(s["x_cb"], d_n1, P["norm1.weight"], s["scale_msa"])
+        dx = self._ew(6, dx1, dxa)
+        dm = torch.cat([dshift_msa, dscale_msa, d_gate_msa, d_crss, dshift_mlp, dscale_mlp, d_gate_mlp], dim=1).contiguous()
+        d_sc = self._lin_bwd(s["sc"], dm, "adaLN_modulation.1", G, 7 * C_, grads)
+        dcond = self._ew(5, d_sc, s["cond_cb"])
+        return _ncdhw(dx, C_), _ncdhw(dcond, G), grads

@@ -25,3 +25,33 @@ def make_inputs(seed, b=2, ps=64, n=2, C=4, srna=4):
     noise = synth.normal(f"train/noise{seed}", tuple(x_pad.shape), seed + 1)
     idx = torch.arange(b)
     return x_pad, (dat, crd, torch.Size([b, cells, cells, srna * 500])), imgs, t, pos, mask, idx, noise
+
+
+# ---- AttnBlock forward + backward cases (tests/golden/train_attn_ref.npz, minted by oracle/make_train_block_golden.py) ----
+ATTN_CASES = {"c64_g24_s16": dict(C=64, G=24, S=16, N=1, seed=5),        # windows of 128 tokens
+              "c32_g20_s8": dict(C=32, G=20, S=8, N=3, seed=9)}          # windows of 32 tokens, G not a multiple of 8
+
+ATTN_SHAPES = lambda C, G: {"norm1.weight": (C,), "norm2.weight": (C,), "attn.q.weight": (C, C), "attn.q.bias": (C,),            # noqa: E731
+                            "attn.k.weight": (C, C), "attn.k.bias": (C,), "attn.v.weight": (C, C), "attn.v.bias": (C,),
+                            "attn.q_norm.weight": (C,), "attn.k_norm.weight": (C,), "attn.proj.weight": (C, C), "attn.proj.bias": (C,),
+                            "mlp.fc1.weight": (4 * C, C), "mlp.fc1.bias": (4 * C,), "mlp.fc2.weight": (C, 4 * C), "mlp.fc2.bias": (C,),
+                            "adaLN_modulation.1.weight": (7 * C, G), "adaLN_modulation.1.bias": (7 * C,)}
+
+
+def make_attn_inputs(name):
+    """-> x [N,C,2,S,S], cond [N,G,2,S,S], dout like x, params {reference key suffix: tensor}; all seeded (synth.normal)."""
+    c = ATTN_CASES[name]
+    C, G, S, N, seed = c["C"], c["G"], c["S"], c["N"], c["seed"]
+    x = synth.normal(f"attn/{name}/x", (N, C, 2, S, S), seed)
+    cond = synth.normal(f"attn/{name}/cond", (N, G, 2, S, S), seed + 1)
+    dout = synth.normal(f"attn/{name}/dout", (N, C, 2, S, S), seed + 2)
+    params = {}
+    for k, shp in ATTN_SHAPES(C, G).items():
+        r = synth.normal(f"attn/{name}/{k}", shp, seed + 3)
+        if k.endswith("norm.weight") or k in ("norm1.weight", "norm2.weight"):
+            params[k] = 1.0 + 0.2 * r
+        elif k.endswith(".bias"):
+            params[k] = 0.1 * r
+        else:
+            params[k] = r / (shp[1] ** 0.5)
+    return x, cond, dout, params
