@@ -337,7 +337,7 @@ int tm_op_conv_wgrad(const void* x_cb8, const void* dy_cb8, void* dw_host, void*
  * tests/test_gpu_train.py checks every gradient against the reference module's own autograd (tests/golden/train_attn_ref.npz). */
 
 /* Elementwise on n floats: op 0 o1 = a + b * c | 1 o1 = a * b, o2 = a * c | 2 o1 = gelu_tanh(a) | 3 o1 = a * gelu_tanh'(b) |
- * 4 o1 = silu(a) | 5 o1 = a * silu'(b) | 6 o1 = a + b. */
+ * 4 o1 = silu(a) | 5 o1 = a * silu'(b) | 6 o1 = a + b | 7 o1 = 4 a | 8 o1 = a / 4. */
 int tm_op_ew(int op, const void* a, const void* b, const void* c, void* o1, void* o2, long n, void* stream);
 
 /* y = RMSNorm_C(x) * norm_w * (1 + scale) + shift with per-voxel scale / shift (CB8 tensors of x's geometry). */
@@ -354,6 +354,24 @@ int tm_op_modnorm_bwd(const void* x_cb8, const void* g_cb8, const void* norm_w_h
 int tm_op_window_attn_train(const void* q_cb8, const void* k_cb8, const void* v_cb8, const void* qw_host,
                             const void* kw_host, const void* dout_cb8, void* o_cb8, void* dq_cb8, void* dk_cb8,
                             void* dv_cb8, void* dqw_host, void* dkw_host, int N, int C, int Z, int S, void* stream);
+
+/* ---- training slice, the small dense pieces: time embedding (model/unet_ours.py:442-476), ResBlock.emb_layers
+ * (model/MBAblocks.py:178-186) and the gene-gene AttnBlock of the RNA pyramid (model/unet_ours.py:277-323) are Linears over
+ * [tokens][features] rows.  DEVICE pointers throughout (fp32), deterministic. */
+
+/* C[b](m, n) = alpha * sum_k A[b](m, k) B[b](k, n) (+ bias[n] if bias_mode 1, bias[m] if 2) (+ C if accumulate), every operand
+ * addressed through element strides strides9 = {sam, sak, sbk, sbn, scm, scn, sab, sbb, scb} (HOST array). */
+int tm_op_gemm_f32(const void* A_dev, const void* B_dev, const void* bias_dev, void* C_dev, int M, int N, int K,
+                   const long* strides9_host, int batch, int bias_mode, int accumulate, float alpha, void* stream);
+
+/* Row-wise ops on [rows][D]: 0 y = RMSNorm_D(x) * w | 1 y = dL/dx of op 0 given g (and dw_dev[D] = dL/dw) | 2 y = softmax_D(x) |
+ * 3 y = x * (g - sum_D(g x)) (softmax backward, x = the saved probabilities). */
+int tm_op_rows(int op, const void* x_dev, const void* w_dev, const void* g_dev, void* y_dev, void* dw_dev, long rows, int D,
+               void* stream);
+
+/* (h, w) resampling of a CB8 tensor: mode 1 nearest x2 (source at S_out / 2), mode 2 AvgPool(1,2,2) (source at 2 S_out)
+ * (model/blocks.py:362-403). */
+int tm_op_resample(const void* x_cb8, void* y_cb8, int N, int C, int Z, int S_out, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -259,6 +259,11 @@ hipError_t launch_attn_train(const TV& q, const TV& k, const TV& v, const float*
                              float* dq, float* dk, float* dv, float* dqw, float* dkw, float* scratch, bool bwd,
                              hipStream_t s);                                            // scratch (bwd): 2 * N * 4 * Cb * 8 floats
 
+hipError_t launch_gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, const long* strides9, int batch,
+                           int bias_mode, int accumulate, float alpha, hipStream_t s);   // strides: sam sak sbk sbn scm scn sab sbb scb
+hipError_t launch_rows(int op, const float* x, const float* w, const float* g, float* y, float* dw, float* scratch, long rows, int D,
+                       hipStream_t s);                                                   // scratch (op 1): ceil(rows / 4) * D floats
+
 // ---- tile I/O (tm_io.hip) --------------------------------------------------------------
 int io_fail(int code, const char* msg);     // sets the tm_last_error() text, returns code
 hipError_t launch_gene_tile_scatter(const int32_t* crd, const float* dat, long nnz, int gblk, int shift_h, int shift_w,

@@ -2137,7 +2137,7 @@ extern "C" int tm_op_prep_bwd(const void* x_cb8, const void* g_cb8, const void* 
 // cin <-> cout transposed (w_host [Cout][Cin][taps] as in the reference state_dict)
 // ---- AttnBlock training pieces (teramind_amd.training.AttnBlockTrain composes them) ----
 extern "C" int tm_op_ew(int op, const void* a, const void* b, const void* c, void* o1, void* o2, long n, void* stream) {
-  if (op < 0 || op > 6 || !a || !o1 || n < 0) return fail(TM_ERR_ARG, "bad argument");
+  if (op < 0 || op > 8 || !a || !o1 || n < 0) return fail(TM_ERR_ARG, "bad argument");
   if ((op == 0 || op == 1) && (!b || !c)) return fail(TM_ERR_ARG, "op %d needs b and c", op);
   if ((op == 3 || op == 5 || op == 6) && !b) return fail(TM_ERR_ARG, "op %d needs b", op);
   if (op == 1 && !o2) return fail(TM_ERR_ARG, "op 1 needs two outputs");
@@ -2229,6 +2229,51 @@ extern "C" int tm_op_window_attn_train(const void* q_cb8, const void* k_cb8, con
   return TM_OK;
 }
 
+extern "C" int tm_op_gemm_f32(const void* A_dev, const void* B_dev, const void* bias_dev, void* C_dev, int M, int N, int K,
+                              const long* strides9_host, int batch, int bias_mode, int accumulate, float alpha, void* stream) {
+  if (!A_dev || !B_dev || !C_dev || !strides9_host || M < 1 || N < 1 || K < 1 || batch < 1 || bias_mode < 0 || bias_mode > 2 ||
+      (bias_mode && !bias_dev))
+    return fail(TM_ERR_ARG, "bad argument");
+  hipError_t e = launch_gemm_f32((const float*)A_dev, (const float*)B_dev, (const float*)bias_dev, (float*)C_dev, M, N, K, strides9_host,
+                                 batch, bias_mode, accumulate, alpha, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "gemm: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
+extern "C" int tm_op_rows(int op, const void* x_dev, const void* w_dev, const void* g_dev, void* y_dev, void* dw_dev, long rows, int D,
+                          void* stream) {
+  if (op < 0 || op > 3 || !x_dev || !y_dev || rows < 1 || D < 1 || D > 8192) return fail(TM_ERR_ARG, "bad argument");
+  if ((op <= 1 && !w_dev) || ((op == 1 || op == 3) && !g_dev) || (op == 1 && !dw_dev)) return fail(TM_ERR_ARG, "op %d: missing operand", op);
+  DevTmp tmp;
+  float* scratch = nullptr;
+  if (op == 1) {
+    scratch = tmp.up(nullptr, 0, (size_t)((rows + 3) / 4) * D);
+    if (!scratch) return fail(TM_ERR_HIP, "device allocation failed");
+  }
+  hipError_t e = launch_rows(op, (const float*)x_dev, (const float*)w_dev, (const float*)g_dev, (float*)y_dev, (float*)dw_dev, scratch, rows, D,
+                             (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "row op: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
+extern "C" int tm_op_resample(const void* x_cb8, void* y_cb8, int N, int C, int Z, int S_out, int mode, void* stream) {
+  if (!x_cb8 || !y_cb8 || (mode != 1 && mode != 2) || (mode == 1 && (S_out & 1))) return fail(TM_ERR_ARG, "bad argument");
+  const int S_in = mode == 1 ? S_out / 2 : S_out * 2;
+  TV x = view_cb8(const_cast<void*>(x_cb8), N, C, Z, S_in, S_in), y = view_cb8(y_cb8, N, C, Z, S_out, S_out);
+  PrepLaunch P;
+  P.nsrc = 1;
+  P.src[0].p = x.p; P.src[0].nstride = x.nstride; P.src[0].Cb = x.Cb;
+  P.resample = mode == 1 ? RS_UP2 : RS_DOWN2;
+  P.N = N; P.Z = Z; P.S = S_out; P.inv_c = 1.0f / (float)C;
+  P.out = y.p; P.out_nstride = y.nstride;
+  hipError_t e = launch_prep(P, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "resample: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
 extern "C" int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx_cb8, int N, int Cin, int Cout, int Z, int S,
                                 int ksize, void* stream) {
   if (!dy_cb8 || !w_host || !dx_cb8 || (ksize != 1 && ksize != 3)) return fail(TM_ERR_ARG, "bad argument");
@@ -2246,7 +2291,7 @@ extern "C" int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx
 extern "C" int tm_op_conv_wgrad(const void* x_cb8, const void* dy_cb8, void* dw_host, void* db_host_or_null, int N, int Cin,
                                 int Cout, int Z, int S, int ksize, void* stream) {
   if (!x_cb8 || !dy_cb8 || !dw_host || (ksize != 1 && ksize != 3)) return fail(TM_ERR_ARG, "bad argument");
-  if (ksize == 3 && Z != 2) return fail(TM_ERR_ARG, "3x3x3 weight gradient: Z must be 2 (the checkpoint model)");
+  if (Z < 1 || Z > 4) return fail(TM_ERR_ARG, "weight gradient: Z must be 1 .. 4 (the kernel stages up to four z planes)");
   const int taps = ksize == 1 ? 1 : 27;
   hipStream_t st = (hipStream_t)stream;
   TV x = view_cb8(const_cast<void*>(x_cb8), N, Cin, Z, S, S), dy = view_cb8(const_cast<void*>(dy_cb8), N, Cout, Z, S, S);

@@ -1,6 +1,6 @@
 // Training slice: backward kernels of one ResBlock (model/MBAblocks.py:237-299,302-368) --
 //   prep_bwd_kernel    backward of  y = Dropout(SiLU(RMSNorm_C(x) * w * (1 + scale) + shift))  (in_layers[0:2], out_layers[0:3])
-//   conv_wgrad_kernel  dW of Conv3d(k = 3x3x3 pad 1, Z == 2) and of the 1x1x1 skip conv
+//   conv_wgrad_kernel  dW of Conv3d(k = 3x3x3 pad 1, Z <= 4) and of the 1x1x1 skip conv
 //   chan_sum_kernel    bias gradients (sum over voxels per channel)
 // The data gradient of the convs (dgrad) needs no kernel of its own: a stride-1 "same" conv's dgrad is the forward conv of
 // dY with the kernel flipped in every axis and cin <-> cout transposed, so it runs on conv3d_mfma / conv1_mfma with weights
@@ -323,6 +323,8 @@ hipError_t launch_chan_sum(const TV& x, float* out, int C, hipStream_t s) {
 //   4 SILU      o1 = silu(a)            adaLN_modulation[0] (MBAblocks.py:463)
 //   5 SILU_BWD  o1 = a * silu'(b)
 //   6 ADD       o1 = a + b
+//   7 MUL4      o1 = 4 a                adjoint of AvgPool(1,2,2) composed from the x2 nearest upsample (and vice versa:
+//   8 DIV4      o1 = a / 4              up2^T = 4 avgpool, avgpool^T = up2 / 4)
 __global__ __launch_bounds__(256) void ew_kernel(int op, const float* a, const float* b, const float* c, float* o1, float* o2, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float av = a[i];
@@ -338,12 +340,14 @@ __global__ __launch_bounds__(256) void ew_kernel(int op, const float* a, const f
       }
       case 4: o1[i] = silu_f(av); break;
       case 5: { const float x = b[i], sg = 1.0f / (1.0f + expf(-x)); o1[i] = av * sg * (1.0f + x * (1.0f - sg)); break; }
-      default: o1[i] = av + b[i]; break;
+      case 6: o1[i] = av + b[i]; break;
+      case 7: o1[i] = 4.0f * av; break;
+      default: o1[i] = 0.25f * av; break;
     }
   }
 }
 hipError_t launch_ew(int op, const float* a, const float* b, const float* c, float* o1, float* o2, long n, hipStream_t s) {
-  if (op < 0 || op > 6 || !a || !o1 || n < 0) return hipErrorInvalidValue;
+  if (op < 0 || op > 8 || !a || !o1 || n < 0) return hipErrorInvalidValue;
   long g = (n + 255) / 256;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
@@ -603,6 +607,135 @@ hipError_t launch_attn_train(const TV& q, const TV& k, const TV& v, const float*
   } else {
     hipLaunchKernelGGL(attn_train_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, s, a);
   }
+  return hipGetLastError();
+}
+
+
+// ==================================================================================================================
+// Small dense pieces of the training path that are not convs over the patch volume: the Linears over [tokens][features]
+// rows (time embedding, ResBlock.emb_layers, the gene-gene AttnBlock of model/unet_ours.py:277-323) and that block's
+// row-wise RMSNorm / softmax.  fp32 VALU, deterministic (no split-K, fixed-order reductions).
+// ==================================================================================================================
+
+// C[b](m, n) = alpha * sum_k A[b](m, k) * B[b](k, n) (+ bias) (+ C): every operand through element strides, so the same kernel
+// serves y = x W^T, dx = dy W, dW = dy^T x, q q^T, P v and their transposes.  64 x 64 tile per workgroup, 4 x 4 per thread.
+struct GemmArgs {
+  const float *A, *B, *bias; float* C;
+  int M, N, K;
+  long sam, sak, sbk, sbn, scm, scn, sab, sbb, scb;
+  int bias_mode;      // 0 none, 1 bias[n], 2 bias[m]
+  int accumulate;     // C += ...
+  float alpha;
+};
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const float* A = a.A + (long)blockIdx.z * a.sab;
+  const float* B = a.B + (long)blockIdx.z * a.sbb;
+  float* Cp = a.C + (long)blockIdx.z * a.scb;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+    for (int e = tid; e < 16 * 64; e += 256) {
+      const int kk = e >> 6, r = e & 63;
+      const int k = k0 + kk;
+      As[kk][r] = (k < a.K && m0 + r < a.M) ? A[(long)(m0 + r) * a.sam + (long)k * a.sak] : 0.f;
+      Bs[kk][r] = (k < a.K && n0 + r < a.N) ? B[(long)k * a.sbk + (long)(n0 + r) * a.sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m >= a.M || n >= a.N) continue;
+      float v = acc[i][j] * a.alpha;
+      if (a.bias_mode == 1) v += a.bias[n];
+      else if (a.bias_mode == 2) v += a.bias[m];
+      float* c = Cp + (long)m * a.scm + (long)n * a.scn;
+      *c = a.accumulate ? *c + v : v;
+    }
+}
+hipError_t launch_gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, const long* st, int batch,
+                           int bias_mode, int accumulate, float alpha, hipStream_t s) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || (bias_mode && !bias)) return hipErrorInvalidValue;
+  GemmArgs a{A, B, bias, C, M, N, K, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], bias_mode, accumulate, alpha};
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)batch), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// Row-wise ops on [rows][D] fp32 (one wave per row, four rows per workgroup):
+//   0 RMSNORM      y = x * rsqrt(mean_d x^2 + eps) * w                                  (LlamaRMSNorm dim=-1, MBAblocks.py:35-43)
+//   1 RMSNORM_BWD  dx = r (g w - xh mean_d(g w xh)),  part[wg][d] = sum over the workgroup's rows of g * xh
+//   2 SOFTMAX      y = softmax_d(x)
+//   3 SOFTMAX_BWD  dx = y_saved * (g - sum_d g y_saved)      (x = the saved probabilities)
+__global__ __launch_bounds__(256) void rows_kernel(int op, const float* x, const float* w, const float* g, float* y, float* part, long rows,
+                                                   int D) {
+  extern __shared__ float sh[];                      // op 1: [4][D] per-row products
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wv;
+  const bool live = r < rows;
+  const float* xr = x + (live ? r : 0) * D;
+  if (op == 0 || op == 1) {
+    float ss = 0.f;
+    if (live) for (int d = lane; d < D; d += 64) ss += xr[d] * xr[d];
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)D + TM_EPS);
+    if (op == 0) {
+      if (live) for (int d = lane; d < D; d += 64) y[r * D + d] = xr[d] * rstd * w[d];
+      return;
+    }
+    float dot = 0.f;
+    if (live) for (int d = lane; d < D; d += 64) dot += g[r * D + d] * w[d] * xr[d] * rstd;
+    dot = wave_sum(dot) / (float)D;
+    for (int d = lane; d < D; d += 64) {
+      float pv = 0.f;
+      if (live) {
+        const float xh = xr[d] * rstd, gv = g[r * D + d];
+        y[r * D + d] = rstd * (gv * w[d] - xh * dot);
+        pv = gv * xh;
+      }
+      sh[wv * D + d] = pv;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) part[(long)blockIdx.x * D + d] = (sh[d] + sh[D + d]) + (sh[2 * D + d] + sh[3 * D + d]);
+    return;
+  }
+  if (!live) return;
+  if (op == 2) {
+    float m = -INFINITY;
+    for (int d = lane; d < D; d += 64) m = fmaxf(m, xr[d]);
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int d = lane; d < D; d += 64) sum += expf(xr[d] - m);
+    sum = wave_sum(sum);
+    for (int d = lane; d < D; d += 64) y[r * D + d] = expf(xr[d] - m) / sum;
+  } else {
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += g[r * D + d] * xr[d];
+    dot = wave_sum(dot);
+    for (int d = lane; d < D; d += 64) y[r * D + d] = xr[d] * (g[r * D + d] - dot);
+  }
+}
+hipError_t launch_rows(int op, const float* x, const float* w, const float* g, float* y, float* dw, float* scratch, long rows, int D,
+                       hipStream_t s) {
+  if (op < 0 || op > 3 || !x || !y || rows < 1 || D < 1 || D > 8192) return hipErrorInvalidValue;
+  if ((op <= 1 && !w) || ((op == 1 || op == 3) && !g) || (op == 1 && (!dw || !scratch))) return hipErrorInvalidValue;
+  const long nwg = (rows + 3) / 4;
+  hipLaunchKernelGGL(rows_kernel, dim3((unsigned)nwg), dim3(256), op == 1 ? (size_t)4 * D * sizeof(float) : 0, s, op, x, w, g, y, scratch, rows, D);
+  if (op == 1) hipLaunchKernelGGL(prep_bwd_reduce_dw_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, s, scratch, nwg, D, dw);
   return hipGetLastError();
 }
 

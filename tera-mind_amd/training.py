@@ -238,9 +238,17 @@ class AttnBlockTrain:
     def forward(self, x: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
         N, Cc, Z, S, _ = x.shape
         assert Cc == self.C and cond.shape[1] == self.G and cond.shape[0] == N and tuple(cond.shape[2:]) == tuple(x.shape[2:])
+        return _ncdhw(self.forward_cb(_cb8(x.to(self.dev).float()), _cb8(cond.to(self.dev).float())), self.C)
+
+    def backward(self, dout: torch.Tensor):
+        dx, dcond, grads = self.backward_cb(_cb8(dout.to(self.dev).float()))
+        return _ncdhw(dx, self.C), _ncdhw(dcond, self.G), grads
+
+    def forward_cb(self, x_cb: torch.Tensor, cond_cb: torch.Tensor) -> torch.Tensor:
+        """CB8 in, CB8 out: x_cb [N, C/8, Z, S, S, 8], cond_cb [N, ceil(G/8), Z, S, S, 8]."""
+        N, _, Z, S, _, _ = x_cb.shape
         P, Cb = self.p, self.C // 8
         self._saved = dict(shape=(N, Z, S))
-        x_cb, cond_cb = _cb8(x.to(self.dev).float()), _cb8(cond.to(self.dev).float())
         sc = self._ew(4, cond_cb)
         m = self._lin(sc, "adaLN_modulation.1", self.G, 7 * self.C)
         shift_msa, scale_msa, gate_msa, crss, shift_mlp, scale_mlp, gate_mlp = (m[:, i * Cb:(i + 1) * Cb].contiguous() for i in range(7))
@@ -258,13 +266,12 @@ class AttnBlockTrain:
         out = self._ew(0, x1, gate_mlp, f)
         self._saved.update(x_cb=x_cb, cond_cb=cond_cb, sc=sc, scale_msa=scale_msa, gate_msa=gate_msa, crss=crss, scale_mlp=scale_mlp,
                            gate_mlp=gate_mlp, n1=n1, q=q, k=k, v=v, o=o, pr=pr, x1=x1, n2=n2, h=h, a=a, f=f)
-        return _ncdhw(out, self.C)
+        return out
 
-    def backward(self, dout: torch.Tensor):
+    def backward_cb(self, g: torch.Tensor):
         s, P = self._saved, self.p
         C_, G, hid = self.C, self.G, self.hid
         grads: Dict[str, torch.Tensor] = {}
-        g = _cb8(dout.to(self.dev).float())
         # out = x1 + gate_mlp * f
         d_f, d_gate_mlp = self._ew(1, g, s["gate_mlp"], s["f"], two=True)
         d_a = self._lin_bwd(s["a"], d_f, "mlp.fc2", hid, C_, grads)
@@ -283,4 +290,4 @@ class AttnBlockTrain:
         dm = torch.cat([dshift_msa, dscale_msa, d_gate_msa, d_crss, dshift_mlp, dscale_mlp, d_gate_mlp], dim=1).contiguous()
         d_sc = self._lin_bwd(s["sc"], dm, "adaLN_modulation.1", G, 7 * C_, grads)
         dcond = self._ew(5, d_sc, s["cond_cb"])
-        return _ncdhw(dx, C_), _ncdhw(dcond, G), grads
+        return dx, dcond, grads

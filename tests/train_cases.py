@@ -55,3 +55,15 @@ def make_attn_inputs(name):
         else:
             params[k] = r / (shp[1] ** 0.5)
     return x, cond, dout, params
+
+
+# ---- whole-model gradient case (tests/golden/train_grad_ref.npz, minted by oracle/make_train_grad_golden.py) ----
+GRAD_CFG = dict(net_ch=16, rna_num=37)          # PathConfig overrides: 16 M parameters, attention at C = 64 (S = 16) and C = 128 (middle)
+GRAD_CASES = {"mse_seed3": (3, "mse", (1, 0))}  # (seed, loss type, crop index (ix, iy))
+GRAD_PROBES = 4
+GRAD_FULL_MAX = 2048                            # tensors up to this many elements are stored whole
+
+
+def grad_probe(key, n, j):
+    from teramind_amd.weights import hashed_uniform
+    return hashed_uniform(f"{key}/probe{j}", n, seed=77)
