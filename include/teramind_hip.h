@@ -373,6 +373,16 @@ int tm_op_rows(int op, const void* x_dev, const void* w_dev, const void* g_dev, 
  * (model/blocks.py:362-403). */
 int tm_op_resample(const void* x_cb8, void* y_cb8, int N, int C, int Z, int S_out, int mode, void* stream);
 
+/* ---- training slice, the optimizer step (experiment.py:207-219 clip_grad_norm_, :394-414 torch.optim.Adam) on one flat fp32
+ * device arena of parameters / gradients / first and second moments. */
+
+/* *out_host = sum of x[i]^2 (two-stage, fixed order). */
+int tm_op_sumsq(const void* x_dev, long n, float* out_host, void* stream);
+
+/* One torch.optim.Adam step (amsgrad off): g' = g * grad_scale + weight_decay * p; m, v, p updated in place; step >= 1. */
+int tm_op_adam(void* p_dev, const void* g_dev, void* m_dev, void* v_dev, long n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

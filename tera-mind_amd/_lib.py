@@ -83,6 +83,8 @@ SIGNATURES = {
     "tm_op_gemm_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] + [c_int] * 3 + [c_float, c_void_p]),
     "tm_op_rows": (c_int, [c_int] + [c_void_p] * 5 + [C.c_long, c_int, c_void_p]),
     "tm_op_resample": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "tm_op_sumsq": (c_int, [c_void_p, C.c_long, c_void_p, c_void_p]),
+    "tm_op_adam": (c_int, [c_void_p] * 4 + [C.c_long] + [c_float] * 5 + [c_int, c_float, c_void_p]),
     "tm_op_modnorm": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "tm_op_modnorm_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p]),
     "tm_op_window_attn_train": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_void_p]),

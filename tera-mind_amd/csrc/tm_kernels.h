@@ -263,6 +263,9 @@ hipError_t launch_gemm_f32(const float* A, const float* B, const float* bias, fl
                            int bias_mode, int accumulate, float alpha, hipStream_t s);   // strides: sam sak sbk sbn scm scn sab sbb scb
 hipError_t launch_rows(int op, const float* x, const float* w, const float* g, float* y, float* dw, float* scratch, long rows, int D,
                        hipStream_t s);                                                   // scratch (op 1): ceil(rows / 4) * D floats
+hipError_t launch_sumsq(const float* x, long n, float* out, float* scratch, int nwg, hipStream_t s);      // scratch: nwg floats
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                       float gscale, hipStream_t s);
 
 // ---- tile I/O (tm_io.hip) --------------------------------------------------------------
 int io_fail(int code, const char* msg);     // sets the tm_last_error() text, returns code

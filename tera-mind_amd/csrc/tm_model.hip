@@ -2274,6 +2274,29 @@ extern "C" int tm_op_resample(const void* x_cb8, void* y_cb8, int N, int C, int 
   return TM_OK;
 }
 
+extern "C" int tm_op_sumsq(const void* x_dev, long n, float* out_host, void* stream) {
+  if (!x_dev || n < 1 || !out_host) return fail(TM_ERR_ARG, "bad argument");
+  const int nwg = (int)std::min<long>(1024, (n + 255) / 256);
+  DevTmp tmp;
+  float* scratch = tmp.up(nullptr, 0, (size_t)nwg + 8);
+  if (!scratch) return fail(TM_ERR_HIP, "device allocation failed");
+  hipError_t e = launch_sumsq((const float*)x_dev, n, scratch + nwg, scratch, nwg, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "sum of squares: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  HIP_TRY(hipMemcpy(out_host, scratch + nwg, sizeof(float), hipMemcpyDeviceToHost));
+  return TM_OK;
+}
+
+extern "C" int tm_op_adam(void* p_dev, const void* g_dev, void* m_dev, void* v_dev, long n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float grad_scale, void* stream) {
+  if (!p_dev || !g_dev || !m_dev || !v_dev || n < 1 || step < 1) return fail(TM_ERR_ARG, "bad argument");
+  hipError_t e = launch_adam((float*)p_dev, (const float*)g_dev, (float*)m_dev, (float*)v_dev, n, lr, beta1, beta2, eps, weight_decay, step,
+                             grad_scale, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(TM_ERR_HIP, "adam: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return TM_OK;
+}
+
 extern "C" int tm_op_conv_dgrad(const void* dy_cb8, const void* w_host, void* dx_cb8, int N, int Cin, int Cout, int Z, int S,
                                 int ksize, void* stream) {
   if (!dy_cb8 || !w_host || !dx_cb8 || (ksize != 1 && ksize != 3)) return fail(TM_ERR_ARG, "bad argument");

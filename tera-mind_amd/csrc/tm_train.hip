@@ -739,4 +739,49 @@ hipError_t launch_rows(int op, const float* x, const float* w, const float* g, f
   return hipGetLastError();
 }
 
+
+// ==================================================================================================================
+// Optimizer step of the reference's training loop (experiment.py:207-219, 394-414): torch.nn.utils.clip_grad_norm_ over all
+// parameters, then torch.optim.Adam(lr, weight_decay) -- on one flat fp32 arena of parameters / gradients / moments.
+// ==================================================================================================================
+
+// part[wg] = sum of squares of this workgroup's grid-stride share, then one thread adds the partials in index order
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* x, long n, float* part) {
+  __shared__ float red[4];
+  float s_ = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s_ = fmaf(x[i], x[i], s_);
+  s_ = wave_sum(s_);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s_;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+hipError_t launch_sumsq(const float* x, long n, float* out, float* scratch, int nwg, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)nwg), dim3(256), 0, s, x, n, scratch);
+  hipLaunchKernelGGL(prep_bwd_reduce_dw_kernel, dim3(1), dim3(64), 0, s, scratch, (long)nwg, 1, out);
+  return hipGetLastError();
+}
+
+// torch.optim.Adam._single_tensor_adam (amsgrad off, maximize off):  g' = g * gscale + wd * p;  m = m + (g' - m)(1 - b1);
+// v = b2 v + (1 - b2) g'^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pv = p[i];
+    const float gv = fmaf(wd, pv, g[i] * gscale);
+    const float mv = m[i] + (gv - m[i]) * (1.0f - b1);
+    const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+    m[i] = mv; v[i] = vv;
+    p[i] = pv - (lr / bc1) * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                       float gscale, hipStream_t s) {
+  if (!p || !g || !m || !v || n < 1 || step < 1) return hipErrorInvalidValue;
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  long grid = (n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), gscale);
+  return hipGetLastError();
+}
+
 }  // namespace tmk

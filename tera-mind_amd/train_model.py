@@ -509,3 +509,51 @@ def training_loss_and_grads(net: UNetTrain, sampler, x_start, r_start, t, loss_m
         g1, g2 = -torch.sign(d1) / per1, -torch.sign(d2) * m_p / per2
     grads = net.backward(g1.contiguous(), g2.contiguous())
     return float(loss), grads
+
+
+class AdamTrainer:
+    """The optimizer half of the reference's training step (experiment.py:207-219, 394-414): clip_grad_norm_(max_norm =
+    conf.grad_clip = 1) over all parameters, then torch.optim.Adam(lr = 2e-5, weight_decay = 0; config_parm.py:48, config.py:
+    76-88) -- on one flat fp32 device arena (parameters, gradients, both moments), two kernels per step (tm_op_sumsq,
+    tm_op_adam).  `accum` micro-batches' gradients are averaged before the step (conf.accum_batches, config_parm.py:45)."""
+
+    def __init__(self, net: UNetTrain, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 grad_clip: float = 1.0):
+        self.net, self.lr, self.betas, self.eps, self.wd, self.clip = net, lr, betas, eps, weight_decay, grad_clip
+        self.keys = list(net.W)
+        self.off, n = {}, 0
+        for k in self.keys:
+            self.off[k] = n
+            n += net.W[k].numel()
+        self.n = n
+        dev = net.dev
+        self.p = torch.cat([net.W[k].reshape(-1) for k in self.keys]).to(dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m, self.v = torch.zeros_like(self.g), torch.zeros_like(self.g)
+        self.t, self._micro = 0, 0
+
+    def accumulate(self, grads: Dict[str, torch.Tensor]):
+        """Adds one micro-batch's gradients (host tensors keyed like the state_dict) into the arena."""
+        flat = torch.cat([grads[k].reshape(-1) for k in self.keys]).to(self.net.dev)
+        self.g = flat if self._micro == 0 else self.net._ew(6, self.g, flat)
+        self._micro += 1
+
+    def step(self) -> Dict[str, float]:
+        """clip + Adam on the accumulated gradients; writes the new parameters back into the model.  Returns the total
+        gradient norm (of the averaged gradient) and the clip coefficient, as clip_grad_norm_ computes them."""
+        if self._micro == 0:
+            raise RuntimeError("AdamTrainer.step: no gradients accumulated")
+        ss = C.c_float(0.0)
+        _lib.check(_lib.lib().tm_op_sumsq(_lib.ptr(self.g), self.n, C.cast(C.byref(ss), C.c_void_p), self.net._st()), "tm_op_sumsq")
+        avg = 1.0 / self._micro
+        total = math.sqrt(ss.value) * avg
+        coef = min(1.0, self.clip / (total + 1e-6)) if self.clip > 0 else 1.0
+        self.t += 1
+        _lib.check(_lib.lib().tm_op_adam(_lib.ptr(self.p), _lib.ptr(self.g), _lib.ptr(self.m), _lib.ptr(self.v), self.n, self.lr, self.betas[0],
+                                         self.betas[1], self.eps, self.wd, self.t, coef * avg, self.net._st()), "tm_op_adam")
+        self._micro = 0
+        host = self.p.cpu()
+        for k in self.keys:
+            self.net.W[k] = host[self.off[k]:self.off[k] + self.net.W[k].numel()].reshape(self.net.W[k].shape).clone()
+        self.net._Wd.clear()
+        return {"grad_norm": total, "clip_coef": coef}

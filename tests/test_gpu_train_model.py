@@ -10,7 +10,7 @@ import torch
 
 from teramind_amd.config import PathConfig
 from teramind_amd.diffusion import SpacedDiffusionBeatGans
-from teramind_amd.train_model import UNetTrain, training_loss_and_grads
+from teramind_amd.train_model import AdamTrainer, UNetTrain, training_loss_and_grads
 from teramind_amd.weights import hashed_state_dict
 from train_cases import GRAD_CASES, GRAD_CFG, GRAD_FULL_MAX, GRAD_PROBES, grad_probe, make_inputs
 
@@ -72,3 +72,46 @@ def test_whole_model_gradients_vs_reference_backward(name):
     # reproducible: the same step again gives the same bits for every tensor (fixed-order reductions, no float atomics)
     loss2, grads2 = training_loss_and_grads(UNetTrain(cfg, sd, DEV), sampler, x_pad, rna, t, mask, noise, crop, cfg.patch_size, loss_type)
     assert loss2 == loss and all(torch.equal(grads2[k], grads[k]) for k in keys)
+
+
+def test_optimizer_step_equals_torch_adam_with_clip():
+    """AdamTrainer (tm_op_sumsq + tm_op_adam on the flat arena) against what the reference's loop calls -- torch.nn.utils.
+    clip_grad_norm_(max_norm=1) and torch.optim.Adam(lr=2e-5, weight_decay=0) (experiment.py:207-219, 394-414) -- on the tiny
+    model's parameters with the gradients of two real training steps (the second after the first update), plus one step with
+    weight decay and two accumulated micro-batches."""
+    cfg = PathConfig(**GRAD_CFG)
+    sd = hashed_state_dict(cfg, 0)
+    x_pad, rna, imgs, t, pos, mask, idx, noise = make_inputs(3)
+    net = UNetTrain(cfg, sd, DEV)
+    sampler = SpacedDiffusionBeatGans(1000, "ddpm")
+    opt = AdamTrainer(net)
+    ref_p = [torch.nn.Parameter(v.clone().float()) for v in sd.values()]
+    ref_opt = torch.optim.Adam(ref_p, lr=2e-5, weight_decay=0)
+    losses = []
+    for step in range(2):
+        loss, grads = training_loss_and_grads(net, sampler, x_pad, rna, t, mask, noise, (1, 0), cfg.patch_size, "mse")
+        losses.append(loss)
+        opt.accumulate(grads)
+        info = opt.step()
+        for p_, k in zip(ref_p, sd):
+            p_.grad = grads[k].clone().reshape(p_.shape)
+        tn = torch.nn.utils.clip_grad_norm_(ref_p, max_norm=1.0)
+        ref_opt.step()
+        assert abs(info["grad_norm"] - float(tn)) <= 1e-5 * float(tn) and info["clip_coef"] < 1.0
+        for p_, k in zip(ref_p, sd):
+            # |update| ~ lr = 2e-5 per step: agree to ~1 % of one update (an fp32 ulp of a parameter near 1 is 1.2e-7)
+            assert torch.allclose(net.W[k], p_.detach(), rtol=0, atol=2.5e-7), (step, k, float((net.W[k] - p_.detach()).abs().max()))
+    assert losses[1] < losses[0]                                   # the same batch again after one step
+    # weight decay, two micro-batches, no clipping
+    opt2 = AdamTrainer(net, lr=1e-3, weight_decay=0.01, grad_clip=0.0)
+    ref_p2 = [torch.nn.Parameter(net.W[k].clone()) for k in sd]
+    ref_opt2 = torch.optim.Adam(ref_p2, lr=1e-3, weight_decay=0.01)
+    g2 = {k: 0.5 * v for k, v in grads.items()}
+    opt2.accumulate(grads)
+    opt2.accumulate(g2)
+    opt2.step()
+    for p_, k in zip(ref_p2, sd):
+        p_.grad = (0.75 * grads[k]).reshape(p_.shape)
+    ref_opt2.step()
+    for p_, k in zip(ref_p2, sd):
+        assert torch.allclose(net.W[k], p_.detach(), rtol=0, atol=1e-3 * 2e-3), (k, float((net.W[k] - p_.detach()).abs().max()))
