@@ -330,7 +330,28 @@ __device__ __forceinline__ void col_to_vox(int T, int i32, int& ps, int& r, int&
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
 
 #ifndef TM_ABL
-#define TM_ABL 0      // diagnostic builds: 1 = no stage barrier, 8 = barrier without waiting for the LDS-DMAs, 2 = no fragment ds_reads after a stage's first tap, 4 = no LDS-DMA after stage 0
+#define TM_ABL 0      // diagnostic builds: 64 = two 16x16x32 MFMAs per 32x32x16 (timing only), 1 = no stage barrier, 8 = barrier without waiting for the LDS-DMAs, 2 = no fragment ds_reads after a stage's first tap, 4 = no LDS-DMA after stage 0
+#endif
+#if TM_ABL & 64
+// timing experiment (results wrong): each 32x32x16 MFMA of the conv27 main loops issued as two 16x16x32 MFMAs on the same
+// operand registers (equal FLOPs, 4-pass instructions) -- what the in-loop clock does with the smaller instruction
+typedef float f32x4_e __attribute__((ext_vector_type(4)));
+#ifdef TM_H16_F16
+#define TM_MFMA16X(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
+#define TM_MFMA16X(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+__device__ __forceinline__ f32x16 mfma_main(bf16x8 a, bf16x8 b, f32x16 c) {
+  f32x4_e c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+  c0 = TM_MFMA16X(a, b, c0);
+  c1 = TM_MFMA16X(a, b, c1);
+  c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+  c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+  return c;
+}
+#define TM_MFMA16_MAIN(a, b, c) mfma_main(a, b, c)
+#else
+#define TM_MFMA16_MAIN(a, b, c) TM_MFMA16(a, b, c)
 #endif
 #ifdef TM_STAMPS
 // Diagnostic build only (make diag -> libteramind_hip_diag.so, tools/conv27_stamps.py): wave 0 of every workgroup records
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv27_bf16(ConvArgsH ah) {
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-          acc[ct][mt] = TM_MFMA16(wf[cur][ct], xf[cur][mt], acc[ct][mt]);
+          acc[ct][mt] = TM_MFMA16_MAIN(wf[cur][ct], xf[cur][mt], acc[ct][mt]);
       __builtin_amdgcn_sched_barrier(0);
       if (more && tap < 4 && !(TM_ABL & 4)) {
         if (NWV == 8) {
@@ -852,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
-            acc[ct][mt] = TM_MFMA16(wf[t][ct], xf[t][mt], acc[ct][mt]);
+            acc[ct][mt] = TM_MFMA16_MAIN(wf[t][ct], xf[t][mt], acc[ct][mt]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PP_STAMP(0);

@@ -138,8 +138,9 @@ class SpacedDiffusionBeatGans:
         genes and the image to it, run the model once (P = 1: the four original patches -> `pred2`, the shifted
         collage patch -> `pred`) and return {'loss', 'x_t'}: mse (or l1) of both predictions against the noise.
         This is the FORWARD of the training step through the inference kernels -- the value a validation pass or a
-        loss curve needs; there is no backward (no gradient kernels), and the model runs as in `.eval()`
-        (the reference's ResBlock dropout p = 0.1, config_parm.py:46, is not applied)."""
+        loss curve needs; the model runs as in `.eval()` (the reference's ResBlock dropout p = 0.1, config_parm.py:46, is
+        not applied).  The same objective WITH gradients and the optimizer step: train_model.training_loss_and_grads /
+        AdamTrainer."""
         import random
         dev = x_start.device
         if noise is None:

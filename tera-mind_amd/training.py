@@ -11,8 +11,11 @@ model/MBAblocks.py:237-299).  This module is the first slice of a native trainin
 and its backward with hand-written kernels: the conv data gradients on the forward MFMA conv kernel (flipped, transposed
 weights), `conv_wgrad_kernel`, `prep_bwd_kernel`, `chan_sum_kernel` (csrc/tm_train.hip).  The dropout keep mask is an
 INPUT (the reference draws it inside nn.Dropout(p=0.1), config_parm.py:46), so that gradients can be compared with
-torch.autograd of the CPU oracle on the same mask.  Not covered yet: the AttnBlock / gene-attention backward, the optimizer,
-EMA, mixed precision -- see DESIGN.md section 8.
+torch.autograd of the CPU oracle on the same mask.  `AttnBlockTrain` is the gene cross-attention block (MBAblocks.py:428-514)
+forward and backward, checked against the reference module's own autograd.  The whole-model training step (both decoder
+passes, the gene-gene attention block, time embedding, loss, clip + Adam) is composed in train_model.py.  Not covered:
+mixed precision (the reference trains under fp16 autocast; this slice is fp32), EMA (commented out upstream,
+experiment.py:200), the data loader -- see DESIGN.md section 8.
 """
 import ctypes as C
 from typing import Dict, Optional

@@ -339,6 +339,29 @@ def test_conv27_16bit_upsampled_input_phase_form_exact_integers(N, Cin, Cout, S,
     assert torch.equal(got.cpu(), ref), util.report("conv27 16-bit upsampled-input " + dtype, got, ref)
 
 
+@pytest.mark.parametrize("dtype,bound", [("bf16", 3.5e-3), ("f16", 4.5e-4)])
+def test_conv27_16bit_upsampled_input_form_rounding_vs_tapwise_rounding(dtype, bound):
+    """The upsampled-input form adds the 3 x 3 in-plane taps of each output phase into 2 x 2 weights in fp32 and rounds the SUM
+    to the 16-bit type; the reference under autocast rounds each of the 27 taps and accumulates the products
+    (round(w1 + w2) x  vs  round(w1) x + round(w2) x).  On random weights the two differ: this records the size.  Against
+    F.conv3d in float64 on the upsampled tensor the two roundings are equally far from the exact-weight result (relative L2
+    1.7e-3 bf16, 2.1e-4 f16 at these shapes) and 2.2e-3 / 2.8e-4 from each other; the bounds leave ~50 % headroom."""
+    td = util.H16[dtype][1]
+    g = torch.Generator().manual_seed(81)
+    N, Cin, Cout, S = 2, 64, 128, 8
+    x = torch.randn((N, Cin, 2, S, S), generator=g).to(td).float()
+    w = torch.randn((Cout, Cin, 3, 3, 3), generator=g) / (Cin * 27) ** 0.5
+    b = torch.zeros((Cout,))
+    xu = x.double().repeat_interleave(2, 3).repeat_interleave(2, 4)
+    exact = F.conv3d(xu, w.double(), b.double(), padding=1)
+    tapwise = F.conv3d(xu, w.to(td).double(), b.double(), padding=1)
+    got, _ = util.conv27_bf16(x.to(DEV), w, b, dtype, ups=True)
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    e_ups, e_tap, e_between = rel(got, exact), rel(tapwise, exact), rel(got, tapwise)
+    assert e_between < bound, (e_between, e_ups, e_tap)
+    assert e_ups < 1.15 * e_tap, (e_ups, e_tap)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_conv27_16bit_residual_at_half_resolution(dtype):
     """res + conv with the residual stored at S/2 and read at (z, y >> 1, x >> 1): the residual of ResBlock(up=True) is the

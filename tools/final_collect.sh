@@ -1,6 +1,6 @@
 #!/bin/bash
 # Turns gpurun_out/final/ (tools/final_measure.sh) into the summaries committed under profiles/.
-# Usage: bash tools/final_collect.sh r02        (run in the build container, from the repo root, on the measured commit)
+# Usage: bash tools/final_collect.sh r03        (run in the build container, from the repo root, on the measured commit)
 set -e
 R=${1:-r02}
 F=gpurun_out/final
@@ -21,10 +21,18 @@ for n in f32 bf16 f16 tile_f32 tile_bf16 tile_f16 sweep_bf16_b16 sweep_bf16_b16_
   echo "## fp32, configs[1]   @ $COMMIT"
   python tools/pmc_summary.py $F/pmc_f32_FETCH_SIZE/pmc_counter_collection.csv $F/pmc_f32_WRITE_SIZE/pmc_counter_collection.csv $F/pmc_f32_SQ/pmc_counter_collection.csv profiles/conv27_traffic.json "conv3d_mfma<2," $COMMIT
   echo; echo "## bf16, configs[1] shape"
-  python tools/pmc_summary.py $F/pmc_bf16_FETCH_SIZE/pmc_counter_collection.csv $F/pmc_bf16_WRITE_SIZE/pmc_counter_collection.csv $F/pmc_bf16_SQ/pmc_counter_collection.csv profiles/conv27_traffic_bf16.json conv27_bf16 $COMMIT
+  python tools/pmc_summary.py $F/pmc_bf16_FETCH_SIZE/pmc_counter_collection.csv $F/pmc_bf16_WRITE_SIZE/pmc_counter_collection.csv $F/pmc_bf16_SQ/pmc_counter_collection.csv profiles/conv27_traffic_bf16.json conv27_ $COMMIT
   echo; echo "## fp32, test_brn tile"
   python tools/pmc_summary.py $F/pmc_tile_f32_FETCH_SIZE/pmc_counter_collection.csv $F/pmc_tile_f32_WRITE_SIZE/pmc_counter_collection.csv $F/pmc_tile_f32_SQ/pmc_counter_collection.csv profiles/conv27_traffic_tile.json "conv3d_mfma<2," $COMMIT
   echo; echo "## bf16, test_brn tile"
-  python tools/pmc_summary.py $F/pmc_tile_bf16_FETCH_SIZE/pmc_counter_collection.csv $F/pmc_tile_bf16_WRITE_SIZE/pmc_counter_collection.csv $F/pmc_tile_bf16_SQ/pmc_counter_collection.csv profiles/conv27_traffic_bf16_tile.json conv27_bf16 $COMMIT
+  python tools/pmc_summary.py $F/pmc_tile_bf16_FETCH_SIZE/pmc_counter_collection.csv $F/pmc_tile_bf16_WRITE_SIZE/pmc_counter_collection.csv $F/pmc_tile_bf16_SQ/pmc_counter_collection.csv profiles/conv27_traffic_bf16_tile.json conv27_ $COMMIT
 } > profiles/${R}_pmc_summary.txt
+{
+  echo "# per-kernel HBM table, bench.py --tile --dtype bf16 (one test_brn tile per step), kernels >= 0.5 % of the step's kernel time   @ $COMMIT"
+  echo "# durations: rocprofv3 --kernel-trace; bytes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x 2, gfx950); peak 8 TB/s"
+  python tools/hbm_table.py $(find $F/prof_tile_bf16 -name "*.db" | head -1) profiles/conv27_traffic_bf16_tile.json
+  echo
+  echo "# the same for bench.py --dtype bf16 (configs[1] shape)"
+  python tools/hbm_table.py $(find $F/prof_bf16 -name "*.db" | head -1) profiles/conv27_traffic_bf16.json
+} > profiles/${R}_kernel_hbm_table.txt
 grep -E "HBM traffic per launch|mfma_busy" profiles/${R}_pmc_summary.txt

@@ -46,9 +46,15 @@ def main():
     # a canvas of plausible values in place of the step-0 noise band: rows of N(0, 0.5) clamped to [-1, 1]
     g = torch.Generator(device=dev)
     g.manual_seed(1)
+    # (one random 64-row band, repeated down the canvas: the time of a step does not depend on the values, and drawing 98 G
+    # normals took minutes of the call's 20)
+    band = None
     for y in range(0, sw.cur.shape[1], 64):
         blk = sw.cur[:, y:y + 64]
-        blk.copy_((torch.randn(blk.shape, generator=g, device=dev, dtype=torch.float32) * 0.5).clamp_(-1, 1))
+        if band is None or band.shape != blk.shape:
+            band = (torch.randn(blk.shape, generator=g, device=dev, dtype=torch.float32) * 0.5).clamp_(-1, 1).to(sw.cur.dtype)
+        blk.copy_(band)
+    del band
     sw.epoch = 1
     torch.cuda.synchronize()
     print(f"[rank_share] canvas {tuple(sw.cur.shape)} fp16 = {sw.cur.numel() * 2 / 1e9:.1f} GB, set-up {time.monotonic() - _T0:.0f} s, "
