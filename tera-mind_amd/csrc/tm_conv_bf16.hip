@@ -44,6 +44,7 @@
 #include "tm_device.h"
 
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace tmk {
@@ -906,6 +907,320 @@ __global__ __launch_bounds__(512, 2) void conv27_pp(ConvArgsH ah) {
   TM_STAMP(3);
 #endif
 #undef PP_STAMP
+}
+
+// ==================================================================================================================
+// conv27_pp16: the ping-pong kernel above on v_mfma_f32_16x16x32 (Z == 2, not the upsampled-input form).
+//
+// Why: with random operands the 4-pass 16x16x32 instruction sustains a higher shader clock than the 8-pass 32x32x16
+// (profiles/r02_micro_mfma16_sustained.txt: 2.05-2.11 vs 1.82-1.87 GHz bare; issuing this kernel's MFMAs as 16x16x32 pairs
+// on the same registers, timing only: +8.6 % over the tile-step layer list, profiles/r03_mfma16x16x32_in_loop.txt).
+//
+// K = 32 per instruction = the 16 channels of a stage x TWO taps.  A stage (channel-block pair, input plane) has 9 taps, so
+// the loop runs over channel-block pairs with BOTH input planes of the pair: 18 taps = 9 UNITS of two taps.  Buffer X holds
+// the pair's first plane, buffer Y its second; units 0-3 read taps (0,1) .. (6,7) of X, unit 4 STRADDLES (tap 8 of X with
+// tap 0 of Y), units 5-8 read taps (1,2) .. (7,8) of Y.  One unit = 4 weight fragments (16 couts x 32 k) + 8 activation
+// fragments (32 k x 16 voxels) = 12 ds_read_b128 and 32 MFMAs (512 matrix-pipe cycles) per wave; the two wave groups alternate
+// unit by unit exactly as in conv27_pp (same barriers, same rolling vmcnt(0) drain).
+// Lane (c16 = lane % 16, q = lane / 16) of a fragment holds k-group q: tap (q / 2) of the unit's two, channels 8 (q % 2) ..+8.
+//   weights:  LDS slot tap * TN * 2 + cout * 2 + (q % 2), UNSWIZZLED (conflict-free for this read pattern: a 16-lane service
+//             group reads couts {0-3, 12-15} of k-half 0 and {4-11} of k-half 1 -> 16 distinct slots mod 16); the packed global
+//             weights keep conv27_bf16's swizzle (the 4-wave tail launches read the same arena), so the LDS-DMA lane that fills
+//             slot (cout, k) fetches global slot (cout, k ^ (cout >> 3 & 1)): a per-lane constant offset, no extra work.
+//   halo:     array (q % 2) at slot(voxel) + shift(tap); the MFMA column -> voxel map (col_to_vox16) puts the 16 voxels of a
+//             tile on 16 distinct slots mod 16 for every tile width (TW = 8: 4 rows x 4 columns at pitch 12).
+// DMA schedule per period of 9 load steps (PPSched16): a piece may be issued from the step after the last unit that reads the
+// slots' old content, and at the latest two steps before the first unit that reads the new one; pieces for Y carry the
+// CURRENT pair's second plane (window [0, first - 2]), pieces for X the NEXT pair's first plane ([last + 1, min(8, 7 + first)]).
+// Epilogue: the 16x16 accumulators (lane: voxel c16, couts 4 q + j of tile a) are converted to the 32x32x16 register layout
+// with one v_permlane16_swap + one v_permlane32_swap per register pair (lane bit 4 <-> tile-column bit, then lane bit 5 <->
+// cout bit 3), after which conv_epilogue_h16 / fused_norm_epilogue run unchanged.
+// ==================================================================================================================
+#ifdef TM_H16_F16
+#define TM_MFMA16K32_ACC(c, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define conv27_pp16 conv27_pp16_f16
+#else
+#define TM_MFMA16K32_ACC(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#endif
+
+template <int TW, int TR>
+__device__ __forceinline__ void col_to_vox16(int T, int i32, int& ps, int& r, int& c) {
+  if (TW == 32) { ps = T / TR; r = T % TR; c = i32; }
+  else if (TW == 16) { ps = T / (TR / 2); r = (T % (TR / 2)) * 2 + (i32 >> 4); c = i32 & 15; }
+  else { ps = T / (TR / 4); r = (T % (TR / 4)) * 4 + ((i32 & 15) >> 2); c = 4 * (i32 >> 4) + (i32 & 3); }
+}
+
+template <int TN, int TW>
+struct PPSched16 {
+  using G = HGeo<TN, TW, 8, false>;
+  static constexpr int NP = G::PW + G::PX;
+  static constexpr int NU = 9, MAXC = 6;
+  __host__ __device__ static constexpr int tap_lo(int p) { return (p * G::NT) / (TN * 2); }
+  __host__ __device__ static constexpr int tap_hi(int p) { const int t = ((p + 1) * G::NT - 1) / (TN * 2); return t > 8 ? 8 : t; }
+  __host__ __device__ static constexpr int unit_x(int t) { return t / 2; }               // tap 8 -> the straddling unit 4
+  __host__ __device__ static constexpr int unit_y(int t) { return 4 + (t + 1) / 2; }     // tap 0 -> unit 4
+  // window of load steps in which piece p for target tgt (0: Y of this pair, 1: X of the next pair) may be issued
+  __host__ __device__ static constexpr int lo(int tgt, int p) { return tgt == 0 ? 0 : (p < G::PW ? unit_x(tap_hi(p)) : 4) + 1; }
+  __host__ __device__ static constexpr int hi(int tgt, int p) {
+    if (tgt == 0) return (p < G::PW ? unit_y(tap_lo(p)) : 4) - 2;
+    const int h = NU + (p < G::PW ? unit_x(tap_lo(p)) : 0) - 2;
+    return h > NU - 1 ? NU - 1 : h;
+  }
+  struct Tbl { int piece[NU][MAXC]; int tgt[NU][MAXC]; int cnt[NU]; bool ok; };
+  __host__ __device__ static constexpr Tbl make() {
+    Tbl t = {};
+    t.ok = true;
+    for (int m = 0; m < NU; ++m) {
+      t.cnt[m] = 0;
+      for (int n = 0; n < MAXC; ++n) { t.piece[m][n] = -1; t.tgt[m][n] = 0; }
+    }
+    // by deadline, halo pieces first; each to the least loaded step of its window (ties: the earliest)
+    for (int dl = 0; dl < NU; ++dl)
+      for (int pass = 0; pass < 2; ++pass)
+        for (int tg = 0; tg < 2; ++tg)
+          for (int q = 0; q < NP; ++q) {
+            if (hi(tg, q) != dl || ((q >= G::PW) != (pass == 0))) continue;
+            if (lo(tg, q) > dl) { t.ok = false; continue; }
+            int best = lo(tg, q);
+            for (int st = lo(tg, q) + 1; st <= dl; ++st)
+              if (t.cnt[st] < t.cnt[best]) best = st;
+            if (t.cnt[best] >= MAXC) { t.ok = false; continue; }
+            t.piece[best][t.cnt[best]] = q;
+            t.tgt[best][t.cnt[best]] = tg;
+            ++t.cnt[best];
+          }
+    return t;
+  }
+};
+
+template <int TN, int TW, bool FUSE>
+__global__ __launch_bounds__(512, 2) void conv27_pp16(ConvArgsH ah) {
+  using G = HGeo<TN, TW, 8, false>;
+  constexpr int NT = G::NT;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const ConvArgs& a = ah.c;
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds16[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const int grp = wvu >> 2;
+  const int i32 = lane & 31, h = lane >> 5;                 // the epilogue's (32x32 layout) lane coordinates
+  const int c16 = lane & 15, kh = (lane >> 4) & 1, hi2 = lane >> 5;   // fragment coordinates: column / row, k-half, which tap of the unit
+  const int wn = wv % G::WNW, wm = wv / G::WNW;
+
+  const int S = a.S;
+  const int tiles_c = S / TW, tiles_r = S / G::TR;
+  const int tiles = tiles_c * tiles_r;
+  const int bid = ah.bid0 + xcd_swizzle(blockIdx.x, gridDim.x);
+  const int nt = bid % a.ntile;
+  int mt_ = bid / a.ntile;
+  const int pg = mt_ / (a.Z * tiles);
+  mt_ -= pg * a.Z * tiles;
+  const int zo = mt_ / tiles;
+  mt_ -= zo * tiles;
+  const int tr = mt_ / tiles_c, tc = mt_ - tr * tiles_c;
+
+  const h16_t* xg = (const h16_t*)a.x;
+  const h16_t* wg = (const h16_t*)a.w;
+  unsigned xvo[G::PX];
+#pragma unroll
+  for (int k = 0; k < G::PX; ++k) {
+    const int i = tid + k * NT;
+    unsigned off = 0x80000000u;
+    if (i < G::XPIECES) {
+      const int half = i / G::XSP;
+      int v = i - half * G::XSP;
+      if (v < G::XS) {
+        const int hc = v % G::HCP; v /= G::HCP;
+        const int hr = v % G::HR;
+        const int ps = v / G::HR;
+        const int n = pg * G::NPB + ps;
+        const int y = tr * G::TR + hr - 1, x = tc * TW + hc - 1;
+        if (hc < G::HC && n < a.N && y >= 0 && y < S && x >= 0 && x < S)
+          off = (unsigned)(((long)ps * ah.x_nstride_e + (long)half * ah.x_plane_e + ((long)y * S + x) * 8) * 2);
+      }
+    }
+    xvo[k] = off;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(xg + (long)pg * G::NPB * ah.x_nstride_e), 0, (int)((long)G::NPB * ah.x_nstride_e * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(wg + (long)nt * ah.Cbp * 27 * TN * 16), 0,
+                                                                       ah.Cbp * 27 * TN * 32, 0x00020000);
+  const int wvo = (tid ^ ((tid >> 4) & 1)) * 16;            // de-swizzling fetch: LDS slot (cout, k) <- packed slot (cout, k ^ (cout >> 3 & 1))
+  // fragment addresses = per-lane base + compile-time offset (the ds_read immediate).  A lane's tap is the unit's first (lanes
+  // 0-31) or second (32-63), so the base carries hi2 * (offset of the second tap - offset of the first): three variants for
+  // the halo (the taps of a unit are neighbours in a row: +1; the pair wraps to the next halo row: + HCP - 2; the straddling
+  // unit: tap 8 of X -> tap 0 of Y), and for the weights (next tap: + TN * 2 slots, from buffer X or buffer Y; the straddle)
+  // LDS regions (16-byte slots): [X weights | X halo | Y halo | Y weights] -- both halo images within one 16-bit ds_read offset
+  // of a per-lane base
+  constexpr int XH = G::WPIECES, YH = G::WPIECES + 2 * G::XSP, YW = G::WPIECES + 4 * G::XSP;
+  static_assert(YW + G::WPIECES == 2 * G::BUF16, "LDS regions");
+  constexpr int XD_ROW = 1, XD_WRAP = G::HCP - 2, XD_STRADDLE = (YH - XH) - (2 * G::HCP + 2);
+  // (the wrap / straddle variants are the row variant + hi2 * const, added where they are used: three of the nine units).
+  // The wave's eight 16-voxel tiles lie at compile-time slot distances from its first (col_to_vox16 is affine over a wave's
+  // four 32-voxel tiles for every geometry), so ONE per-lane base register serves all eight fragment reads of a unit.
+  int xb0;
+  {
+    int ps, r, c;
+    col_to_vox16<TW, G::TR>(wm * 4, c16, ps, r, c);
+    xb0 = G::WPIECES + kh * G::XSP + (ps * G::HR + r) * G::HCP + c + hi2 * XD_ROW;
+  }
+  auto tile_delta = [](int b) constexpr {                    // slot distance of tile b = 2 mt + bq from tile 0
+    const int mt = b >> 1, bq = b & 1;
+    if (TW == 32) return mt * G::HCP + 16 * bq;
+    if (TW == 16) return (2 * mt + bq) * G::HCP;
+    return ((mt >> 1) * G::HR + (mt & 1) * 4) * G::HCP + 4 * bq;
+  };
+  static_assert(TW != 32 || G::TR % 4 == 0, "tile map"); static_assert(TW != 16 || (G::TR / 2) % 4 == 0, "tile map");
+  static_assert(TW != 8 || G::TR / 4 == 2, "tile map");
+  const int wb = (wn * 64 + c16) * 2 + kh;
+  const int wbA = wb + hi2 * TN * 2;                     // (the Y and straddle variants: wbA + a per-unit add, below)
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[ca][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // Z == 2: both input planes feed both output planes -- tap plane kz = zi + 1 - zo
+  auto issue_piece = [&](int tgt, int cbp, int p) __attribute__((always_inline)) {
+    u32x4* wbase = lds16 + (tgt == 0 ? YW : 0);
+    u32x4* hbase = lds16 + (tgt == 0 ? YH : XH);
+    const int zi = tgt == 0 ? 1 : 0;
+    if (p < G::PW) {
+      const int ws = (cbp * 3 + (zi + 1 - zo)) * 9 * TN * 32;
+      if (G::WPIECES % NT == 0 || p * NT + wvu * 64 < G::WPIECES) TM_BLDS16(wrs, wvo, ws + p * NT * 16, wbase + p * NT + wvu * 64);
+    } else {
+      const int k = p - G::PW;
+      const int xs = (cbp * 2 * (int)ah.x_plane_e + zi * S * S * 8) * 2;
+      if (G::XPIECES % NT == 0 || k * NT + wvu * 64 < G::XPIECES) TM_BLDS16(xrs, xvo[k], xs, hbase + k * NT + wvu * 64);
+    }
+  };
+  using SCH = PPSched16<TN, TW>;
+  constexpr int NP = SCH::NP;
+  constexpr typename SCH::Tbl sch = SCH::make();
+  static_assert(sch.ok, "PPSched16: a piece has no admissible load step");
+
+  // prologue: the first pair's plane 0 into buffer X (its plane 1 arrives through the load steps 0 .. 6 like every Y)
+#pragma unroll
+  for (int p = 0; p < NP; ++p) issue_piece(1, 0, p);
+  __syncthreads();
+
+  bf16x8 wf[4], xf[8];
+  const int NPAIR = ah.Cbp;
+  // load step of unit m: retire this wave's older pieces, then the unit's 12 fragment reads with this step's pieces between them;
+  // cy / cx: the pair whose Y / X pieces are issued (cx < 0: none)
+  auto load_step = [&](auto mc, int cy, int cx) __attribute__((always_inline)) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int t1 = m < 4 ? 2 * m : (m == 4 ? 8 : 2 * (m - 4) - 1), t2 = m < 4 ? 2 * m + 1 : (m == 4 ? 0 : 2 * (m - 4));
+    constexpr int b1 = m <= 4 ? 0 : YH - XH;
+    constexpr int sh1 = (t1 / 3) * G::HCP + (t1 % 3), sh2 = (t2 / 3) * G::HCP + (t2 % 3);
+    constexpr int xk = m == 4 ? 2 : (sh2 - sh1 == XD_ROW ? 0 : 1);           // which halo base variant
+    static_assert(m == 4 || sh2 - sh1 == XD_ROW || sh2 - sh1 == XD_WRAP, "tap pair geometry");
+    static_assert(m == 4 || t2 == t1 + 1, "tap pair");
+    constexpr int xo = b1 + sh1;                                               // immediate part, in 16-byte slots
+    constexpr int wo = t1 * TN * 2;                                            // (the Y weights' base is in wbY: the offset field is 16 bits)
+    static_assert((xo + tile_delta(7) + 1) * 16 < 65536 && (wo + 3 * 32 + 1) * 16 < 65536, "ds_read offset field");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int xbu = xb0;
+    if (xk != 0) {
+      int d = hi2 * ((xk == 1 ? XD_WRAP : XD_STRADDLE) - XD_ROW);
+      asm volatile("" : "+v"(d));                      // keeps the add inside the unit
+      xbu += d;
+    }
+    int wd = m == 4 ? hi2 * (YW - 9 * TN * 2) : (m < 4 ? 0 : YW);
+    if (m >= 4) asm volatile("" : "+v"(wd));
+    const int wsel = wbA + wd + wo;
+    auto pieces = [&](int n) __attribute__((always_inline)) {
+      if (n < sch.cnt[m]) {
+        const int tg = sch.tgt[m][n];
+        if (tg == 0) issue_piece(0, cy, sch.piece[m][n]);
+        else if (cx >= 0) issue_piece(1, cx, sch.piece[m][n]);
+      }
+    };
+    pieces(0);
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca) wf[ca] = __builtin_bit_cast(bf16x8, lds16[wsel + ca * 32]);
+    __builtin_amdgcn_sched_barrier(0);
+    pieces(1);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xf[b] = __builtin_bit_cast(bf16x8, lds16[xbu + (xo + tile_delta(b))]);
+    __builtin_amdgcn_sched_barrier(0);
+    pieces(2);
+#pragma unroll
+    for (int b = 4; b < 8; ++b) xf[b] = __builtin_bit_cast(bf16x8, lds16[xbu + (xo + tile_delta(b))]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 3; n < SCH::MAXC; ++n) pieces(n);
+  };
+  load_step(std::integral_constant<int, 0>{}, 0, NPAIR > 1 ? 1 : -1);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0) only
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one interval behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int cb = 0; cb < NPAIR; ++cb) {
+    const bool more = cb + 1 < NPAIR;
+    const int cx = more ? cb + 1 : -1;
+    auto unit = [&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) TM_MFMA16K32_ACC(acc[ca][b], wf[ca], xf[b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(m == 8 && !more && grp == 1)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < 8) load_step(std::integral_constant<int, (m < 8 ? m + 1 : 0)>{}, cb, cx);
+      else if (more) load_step(std::integral_constant<int, 0>{}, cb + 1, cb + 2 < NPAIR ? cb + 2 : -1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{}); unit(std::integral_constant<int, 2>{});
+    unit(std::integral_constant<int, 3>{}); unit(std::integral_constant<int, 4>{}); unit(std::integral_constant<int, 5>{});
+    unit(std::integral_constant<int, 6>{}); unit(std::integral_constant<int, 7>{}); unit(std::integral_constant<int, 8>{});
+  }
+
+  // The MFMAs above are inline asm with the accumulator TIED (dst = src C): left to the register allocator, the 32 four-register
+  // accumulators wandered through the whole file and the LDS-DMA offsets were spilled to scratch inside the loop (each reload
+  // an s_waitcnt vmcnt(0) that also waits for the pieces just issued).  The hazard recogniser does not see inside inline asm:
+  // the last MFMA's result needs its passes before a VALU instruction may read it.
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  // output coordinates of the epilogue's lanes (computed here: eight registers the loop does not have to carry)
+  int on[4], ooff[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int ps, r, c;
+    col_to_vox16<TW, G::TR>(wm * 4 + mt, i32, ps, r, c);
+    const int n = pg * G::NPB + ps;
+    on[mt] = n;
+    const int y = tr * G::TR + r, x = tc * TW + c;
+    ooff[mt] = (n < a.N) ? ((zo * S + y) * S + x) * 8 : -1;
+  }
+  // 16x16 tiles -> the 32x32x16 accumulator layout of the epilogues
+  f32x16 acc32[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xv = acc[2 * ct + ap][2 * mt][j], yv = acc[2 * ct + ap][2 * mt + 1][j];
+          const auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(xv), __float_as_uint(yv), false, false);
+          const auto s2 = __builtin_amdgcn_permlane32_swap(s1[0], s1[1], false, false);
+          acc32[ct][mt][8 * ap + j] = __uint_as_float(s2[0]);
+          acc32[ct][mt][8 * ap + 4 + j] = __uint_as_float(s2[1]);
+        }
+  if (FUSE) fused_norm_epilogue<G::WNW>(ah, acc32, wn, wm, i32, h, on, ooff, (float*)lds16);
+  else conv_epilogue_h16<false>(a, acc32, (nt * G::WNW + wn) * 8, h, on, ooff);
 }
 
 #ifdef TM_STAMPS
@@ -1913,6 +2228,9 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   static const int tail_split = [] { const char* e = getenv("TM_CONV27_TAIL_SPLIT"); return e ? atoi(e) : 1; }();     // A/B switch
   const long ncu = cu_count();
   long grid_override = 0;
+  // TM_CONV27_K32=0 (environment, read once): the 32x32x16 ping-pong kernel instead of the 16x16x32 one (A/B); Z != 2 always
+  static const int env_k32 = [] { const char* e = getenv("TM_CONV27_K32"); return e ? atoi(e) : 1; }();
+  const bool use_k32 = env_k32 != 0 && a.Z == 2;
   const int fw27 = L.force_waves == 9 ? 8 : (L.force_waves ? L.force_waves : env27);
   if (fw27 != 0 && fw27 != 4 && fw27 != 8) return hipErrorInvalidValue;
 #define TM_LAUNCHH(TN_, TW_)                                                                     \
@@ -1954,7 +2272,19 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     const long tiles = (long)(S / TW_) * (S / G::TR);                                           \
     const long pgs = (a.N + G::NPB - 1) / G::NPB;                                               \
     const long grid = grid_override ? grid_override : pgs * a.Z * tiles * a.ntile;              \
-    if (ah.fuse) hipLaunchKernelGGL((conv27_pp<TN_, TW_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+    if (use_k32) {                                                                              \
+      static DevOnce attr16_done;                                                               \
+      if (attr16_done.need()) {                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)conv27_pp16<TN_, TW_, false>,           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv27_pp16<TN_, TW_, true>,  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); \
+        if (e != hipSuccess) return e;                                                          \
+        attr16_done.mark();                                                                     \
+      }                                                                                         \
+      if (ah.fuse) hipLaunchKernelGGL((conv27_pp16<TN_, TW_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+      else hipLaunchKernelGGL((conv27_pp16<TN_, TW_, false>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
+    } else if (ah.fuse) hipLaunchKernelGGL((conv27_pp<TN_, TW_, true>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
     else hipLaunchKernelGGL((conv27_pp<TN_, TW_, false>), dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, s, ah); \
   } while (0)
 #define TM_LAUNCHHW(TN_, TW_, NWV_)                                                              \
