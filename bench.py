@@ -126,7 +126,7 @@ def roofline_block(prof, dtype, dt_total, value_per_gpu, P, tile, sweep=False):
     whole = NEEDED_GFLOP[P] * Z_AWARE * value_per_gpu / 1e3          # z-aware needed TFLOP/s of the whole step, per GPU
     return {"bound": "mfma",
             "kernel": ("conv3d_mfma<2,*,*> (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x2_f32)" if dtype == "f32"
-                       else f"conv27_{dtype} (3x3x3 implicit-GEMM Conv3d, v_mfma_f32_32x32x16_{dtype})"),
+                       else f"conv27_{dtype} (3x3x3 implicit-GEMM Conv3d: conv27_pp16 on v_mfma_f32_16x16x32_{dtype}; upsampled-input form, 4-wave forms and tail launches on v_mfma_f32_32x32x16_{dtype})"),
             # MFMA FLOPs actually issued (the structurally-zero z tap of the Z = 2 model is never staged nor multiplied:
             # 2/3 of the dense-conv count) / launch duration, against the dense peak: <= 1 by construction
             "achieved": round(executed, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
