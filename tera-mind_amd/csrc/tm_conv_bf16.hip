@@ -2225,7 +2225,7 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
   if (L.fuse_norm && (a.ntile != 1 || L.Cout != TN || L.a2.Cb != TN / 8 || L.res || L.res_h)) return hipErrorInvalidValue;
   if (S != 8 && S != 16 && S != 32 && S != 64 && S != 128) return hipErrorInvalidValue;
   static const int env27 = env_waves("TM_CONV27_WAVES");
-  static const int tail_split = [] { const char* e = getenv("TM_CONV27_TAIL_SPLIT"); return e ? atoi(e) : 1; }();     // A/B switch
+  static const int tail_split = [] { const char* e = getenv("TM_CONV27_TAIL_SPLIT"); return e ? atoi(e) : 80; }();     // A/B switch (0 off, 1 <= ncu, else percent of 2 ncu)
   const long ncu = cu_count();
   long grid_override = 0;
   // TM_CONV27_K32=0 (environment, read once): the 32x32x16 ping-pong kernel instead of the 16x16x32 one (A/B); Z != 2 always
@@ -2249,7 +2249,10 @@ hipError_t launch_conv27_bf16(const ConvLaunchH& L, hipStream_t s) {
     const long full = grid8 / ncu * ncu / unit * unit;                                          \
     const long grid4 = ((a.N + G4::NPB - 1) / G4::NPB) * a.Z * ((long)(S / TW_) * (S / G4::TR)) * a.ntile; \
     const long tail4 = grid4 - 2 * full;                                                        \
-    if (w8 && use_pp && fw27 == 0 && tail_split && full >= ncu && tail4 > 0 && tail4 <= ncu) {  \
+    /* Two 4-wave workgroups fit a CU side by side (2 x LDS_BYTES <= 160 KB), so a tail of up to tail_pct % of 2 ncu half-tiles */ \
+    /* is still resident all at once (TM_CONV27_TAIL_SPLIT = that percentage; 1 = the round-3a rule: at most ncu).            */ \
+    const long tail_cap = tail_split == 1 ? ncu : (2 * G4::LDS_BYTES <= 160 * 1024 ? 2 * ncu * tail_split / 100 : ncu);  \
+    if (w8 && use_pp && fw27 == 0 && tail_split && full >= ncu && tail4 > 0 && tail4 <= tail_cap) {  \
       grid_override = full;                                                                     \
       TM_LAUNCHPP(TN_, TW_);                                                                    \
       ah.bid0 = (int)(2 * full); grid_override = tail4;                                         \
