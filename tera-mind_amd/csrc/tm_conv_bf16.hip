@@ -54,7 +54,7 @@ typedef h16_t bf16x8 __attribute__((ext_vector_type(8)));      // 8 x 16-bit flo
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector (HIP's uint4 class resists SROA)
 
 // SiLU / tanh-GELU on the hardware exp2 / rcp (1 ulp each) for results that are rounded to a 16-bit type right away
-__device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_fast(float x) { return silu_h16(x); }
 // 0.5 x (1 + tanh u) = x / (1 + e^{-2u}),  u = sqrt(2/pi) (x + 0.044715 x^3);  -2u log2(e) = x (k0 + k1 x^2): two multiplies,
 // one FMA and one add around the two transcendentals (the epilogue of fc1 is VALU-bound on this: 4C values per voxel)
 __device__ __forceinline__ float gelu_tanh_fast(float x) {

@@ -35,6 +35,12 @@ struct DevOnce {
 #endif
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// SiLU for results that are rounded to a 16-bit type right away: v_exp_f32 and v_rcp_f32 (1 ulp each).  NOT `__frcp_rn`, which
+// is an IEEE division on this compiler (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ten VALU instructions per
+// value; the block-input passes and the fused conv epilogue were VALU-bound on it, profiles/r03_silu_rcp.txt)
+__device__ __forceinline__ float silu_h16(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float kBeta = 0.7978845608028654f;   // sqrt(2/pi)
   const float kKappa = 0.044715f;

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         if (L.mod != MOD_NONE) v = v * (1.0f + sc[j]) + sh[j];
         // SiLU: exact expf / division where the result stays fp32; hardware exp2 / rcp (1 ulp) where it is rounded to a
         // 16-bit type anyway (the 16-bit modes: 8 or 11 significant bits survive)
-        if (L.act) v = L.out_h ? v * __frcp_rn(1.0f + __expf(-v)) : silu_f(v);
+        if (L.act) v = L.out_h ? silu_h16(v) : silu_f(v);
         if (L.drop_mask) v *= L.drop_mask[(long)n * L.drop_ns + (long)gb * oplane + oin + j] * L.drop_scale;
         o[j] += v;
       }
@@ -844,19 +844,19 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
   const int cb0 = L.src[0].Cb, cb01 = cb0 + ((L.nsrc > 1) ? L.src[1].Cb : 0);
   const int cbtot = cb01 + ((L.nsrc > 2) ? L.src[2].Cb : 0);
   const int g0 = WS == 4 ? wv : 0;                          // this wave's virtual blocks: g0, g0 + WS, ...
+  // Every one of the NB loads is issued UNCONDITIONALLY (a block past the end re-reads the last real block, an invalid lane reads
+  // voxel 0's entry: a cache hit, the value is never used): with the loads under `if (gb < cbtot)` the register allocator
+  // kept three copies of the block array alive across the branches (234 VGPRs for NB = 16, two waves per SIMD)
   pu32x4 c[NB];
-  if (valid) {
+  const int glast = g0 < cbtot ? cbtot - 1 - ((cbtot - 1 - g0) % WS) : 0;      // the wave's last real block (block 0 if it has none)
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int gb = g0 + WS * i;
-      if (gb < cbtot) {
-        const int k = (gb >= cb0) + (gb >= cb01);              // wave-uniform
-        const int cb = gb - (k == 0 ? 0 : (k == 1 ? cb0 : cb01));
-        const uint16_t* sp = (const uint16_t*)(k == 0 ? L.src[0].p : (k == 1 ? L.src[1].p : L.src[2].p));
-        const long so = k == 0 ? soff[0] : (k == 1 ? soff[1] : soff[2]);
-        c[i] = *(const pu32x4*)(sp + so + (long)cb * splane);
-      }
-    }
+  for (int i = 0; i < NB; ++i) {
+    const int gb = min(g0 + WS * i, glast);
+    const int k = (gb >= cb0) + (gb >= cb01);              // wave-uniform
+    const int cb = gb - (k == 0 ? 0 : (k == 1 ? cb0 : cb01));
+    const uint16_t* sp = (const uint16_t*)(k == 0 ? L.src[0].p : (k == 1 ? L.src[1].p : L.src[2].p));
+    const long so = k == 0 ? soff[0] : (k == 1 ? soff[1] : soff[2]);
+    c[i] = *(const pu32x4*)(sp + so + (long)cb * splane);
   }
   float rstd = 1.f;
   if (L.norm_w) {
@@ -873,6 +873,7 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) ps[WS == 4 ? 0 : (i & 3)] += f[j] * f[j];
         }
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four blocks' floats live at a time, not all NB x 8 of them
       }
     }
     float ssq;
@@ -905,12 +906,13 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
     if (L.mod == MOD_VOXEL) {
 #pragma unroll
       for (int ii = 0; ii < CH; ++ii) {
-        const int gb = g0 + WS * (i0 + ii);
-        if (i0 + ii < NB && gb < cbtot) {
-          msc[ii] = *(const pu32x4*)(L.mod_scale_h + mo + (long)gb * mplane);
-          msh[ii] = *(const pu32x4*)(L.mod_shift_h + mo + (long)gb * mplane);
-        }
+        const int gb = min(g0 + WS * (i0 + ii), glast);        // unconditional, as the source loads above
+        msc[ii] = *(const pu32x4*)(L.mod_scale_h + mo + (long)gb * mplane);
+        msh[ii] = *(const pu32x4*)(L.mod_shift_h + mo + (long)gb * mplane);
       }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii) { msc[ii] = pu32x4{0u, 0u, 0u, 0u}; msh[ii] = pu32x4{0u, 0u, 0u, 0u}; }
     }
 #pragma unroll
     for (int ii = 0; ii < CH; ++ii) {
@@ -943,11 +945,12 @@ __global__ __launch_bounds__(256) void prep_h16_kernel(PrepArgs pa) {
         }
         if (L.act) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * __frcp_rn(1.0f + __expf(-v[j]));
+          for (int j = 0; j < 8; ++j) v[j] = silu_h16(v[j]);
         }
         *(pu32x4*)(outp + (long)gb * oplane) = pack8<F16>(v);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);       // one chunk at a time: without it the bf16 build unpacks every block up front (234 VGPRs)
   }
   if (L.pad_blocks && (WS == 1 || wv == 0)) {
     for (int pb = 0; pb < L.pad_blocks; ++pb) {
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(256) void prep_down_h16_kernel(PrepArgs pa) {
         for (int j = 0; j < 8; ++j) {
           r[j] += v[j];
           float t = L.norm_w ? wn[j] * (v[j] * rstd[sub]) : v[j];
-          if (L.act) t = t * __frcp_rn(1.0f + __expf(-t));
+          if (L.act) t = silu_h16(t);
           o[j] += t;
         }
       }
