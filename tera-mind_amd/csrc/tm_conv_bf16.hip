@@ -356,6 +356,74 @@ __device__ __forceinline__ void conv1_epilogue_stream(const ConvArgs& a, f32x16 
   }
 }
 
+// Kind 3 of the stream epilogue (16-bit gate at full or half resolution + 16-bit residual, x <- x + gate * Linear(.)).  Order
+//   L0 C0 L1 S0 C1 L2 S1 C2 L3 S2 C3 S3   (L = a round's eight loads, C = its arithmetic, S = its four stores):
+// round r's stores leave BEHIND round r + 1's loads, so the wait in front of C(r+1) is vmcnt(4) -- it never waits for a store to
+// be acknowledged (the round-by-round form L C S L C S ... did, four write round trips in series).  Holding one round's rounded
+// results (16 registers) is all it costs; the forms that keep every result to the end or double-buffer the loads need more
+// than 256 VGPRs next to the accumulators and spill (measured 4 x slower).  Addresses: per-voxel byte pointer, computed once
+// per voxel tile, + cout block x plane bytes.
+__device__ __forceinline__ void conv1_epilogue_gated(const ConvArgs& a, f32x16 (&acc)[2][4], int cob0, int h,
+                                                     const int (&on)[4], const int (&ooff_in)[4]) {
+  typedef h16_t h16x8 __attribute__((ext_vector_type(8)));
+  const char* rbase[4];
+  const char* gbase[4];
+  char* ybase[4];
+  bool okv[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int oo = ooff_in[mt], nn = on[mt];
+    asm volatile("" : "+v"(oo), "+v"(nn));            // after the K loop: keeps the address arithmetic from being hoisted over it
+    okv[mt] = oo >= 0;
+    const long n = okv[mt] ? nn : 0;
+    const int o1 = okv[mt] ? oo : 0;
+    rbase[mt] = (const char*)(a.res_h + n * a.res_h_nstride + o1);
+    gbase[mt] = (const char*)(a.gate_h + n * a.gate_h_nstride + (a.gate_ls ? half_res_off(o1, a.gate_ls) : o1));
+    ybase[mt] = (char*)(a.y_h + n * a.yh_nstride + o1);
+  }
+  const long ypl = (long)a.y_plane * 2, gpl = a.gate_ls ? ypl >> 2 : ypl;        // bytes per cout block
+  h16x8 rb[4], gb[4], ob[4];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    if (r < 4) {
+      const int cob = min(cob0 + (r >> 1) * 4 + 2 * (r & 1) + h, a.Cob - 1);      // a block past the end re-reads the last one
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        rb[mt] = *(const h16x8*)(rbase[mt] + cob * ypl);
+        gb[mt] = *(const h16x8*)(gbase[mt] + cob * gpl);
+      }
+    }
+    if (r >= 1) {                                     // S(r - 1), behind L(r)
+      const int cob = cob0 + ((r - 1) >> 1) * 4 + 2 * ((r - 1) & 1) + h;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        if (cob < a.Cob && okv[mt]) *(h16x8*)(ybase[mt] + cob * ypl) = ob[mt];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (r < 4) {                                      // C(r)
+      const int ct = r >> 1, q = r & 1;
+      const int cob = min(cob0 + ct * 4 + 2 * q + h, a.Cob - 1);
+      const f32x4 b0 = *(const f32x4*)(a.bias + (long)cob * 8), b1 = *(const f32x4*)(a.bias + (long)cob * 8 + 4);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xq = acc[ct][mt][8 * q + j], yq = acc[ct][mt][8 * q + 4 + j];
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xq), __float_as_uint(yq), false, false);
+          o[j] = __uint_as_float(sw[0]) + b0[j];
+          o[4 + j] = __uint_as_float(sw[1]) + b1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] *= (float)gb[mt][j]; o[j] = (float)rb[mt][j] + o[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ob[mt][j] = (h16_t)o[j];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Activation image in LDS: two arrays (k-half 0 / 1) of 16-byte slots [patch][halo row][pitch]; a lane reads
 // slot(vox) of array h.  ds_read_b128 is served in the 16-lane groups G1 = {0-3,12-15,20-27} and
 // G2 = {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS table) and is conflict-free when a group's 16 slots are
@@ -1519,6 +1587,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   TM_STAMP(2);
   const int cob0 = (nt * G::WNW + wn) * 8;
   if (EK == 0) conv_epilogue_h16<true>(a, acc, cob0, h, on, ooff);
+  else if (EK == 3) conv1_epilogue_gated(a, acc, cob0, h, on, ooff);
   else conv1_epilogue_stream<EK>(a, acc, cob0, h, on, ooff);
 #ifdef TM_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2214,8 +2283,9 @@ hipError_t launch_conv1_bf16(const ConvLaunchH& L, hipStream_t s) {
     else if (ek == 3) hipLaunchKernelGGL((conv1_bf16<TN_, NWV_, false, 3>), g_, b_, G::LDS_BYTES, s, ah, zp, cx); \
     else hipLaunchKernelGGL((conv1_bf16<TN_, NWV_, false, 0>), g_, b_, G::LDS_BYTES, s, ah, zp, cx); \
   } while (0)
-  // epilogue kind (conv1_epilogue_stream): 16-bit stream output without fp32 side inputs; TM_CONV1_EK=0 forces the generic one (A/B)
-  static const int env_ek = [] { const char* e = getenv("TM_CONV1_EK"); return e ? atoi(e) : 1; }();   // 2: kind 3 too
+  // epilogue kind (conv1_epilogue_stream / _gated): 16-bit stream output without fp32 side inputs; TM_CONV1_EK=0 forces the
+  // generic one (A/B)
+  static const int env_ek = [] { const char* e = getenv("TM_CONV1_EK"); return e ? atoi(e) : 2; }();   // 1: kinds 1 and 2 only
   const bool stream = env_ek != 0 && a.y_h && !a.gate && !a.res;
   const bool gelu = (a.flags & EPI_GELU) != 0;
   int ek = 0;
