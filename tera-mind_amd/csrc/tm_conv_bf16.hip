@@ -1453,7 +1453,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   // a channel-block plane and its patch index, as they stand and (multi-source input) after the collage remap.
   long xoff[G::PX];
   int xkp[G::PX], xhalf[G::PX];
-  int xn[G::PX], xo[G::PX], xnc[G::PX], xoc[G::PX];     // multi-source only
+  // multi-source only: per source and piece, the voxel's element offset inside the source (patch stride x patch + in-plane
+  // offset, through the collage remap if the source is collaged), -1 for a voxel past the end.  Computed here, once: in
+  // the K loop a piece costs two selects, one 64-bit add and the scalar block term (the 64-bit multiplies per piece and
+  // stage that stood there made a stage 3 000-3 200 cycles against 2 300-2 500 of the single-source kernel)
+  long xbase[3][G::PX];
   constexpr bool multi = MS;
   const h16_t *ms_p0 = (const h16_t*)cx.p0, *ms_p1 = (const h16_t*)cx.p1p, *ms_p2 = (const h16_t*)cx.p2p;
   const long ms_ns0 = cx.ns0, ms_ns1 = cx.ns1, ms_ns2 = cx.ns2;
@@ -1470,7 +1474,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
     xhalf[k] = half;
     const long vg = (long)mtile * G::TM + v;
     long off = -1;
-    xn[k] = -1; xo[k] = 0; xnc[k] = 0; xoc[k] = 0;
+    xbase[0][k] = -1; xbase[1][k] = -1; xbase[2][k] = -1;
     if (vg < vtot) {
       const long n = vg / VPN;
       const int rem = (int)(vg - n * VPN);
@@ -1485,8 +1489,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
         int ys = y + S / 2, xs = x + S / 2;
         if (ys >= S) { ys -= S; pi += 1; }
         if (xs >= S) { xs -= S; pj += 1; }
-        xn[k] = (int)n; xo[k] = rem * 8;
-        xnc[k] = bi * ms_pp1 * ms_pp2 + pi * ms_pp2 + pj; xoc[k] = ((z * S + ys) * S + xs) * 8;
+        const long nc = bi * ms_pp1 * ms_pp2 + pi * ms_pp2 + pj;
+        const int oc = ((z * S + ys) * S + xs) * 8;
+        xbase[0][k] = ms_col0 ? nc * ms_ns0 + oc : n * ms_ns0 + rem * 8;
+        xbase[1][k] = ms_col1 ? nc * ms_ns1 + oc : n * ms_ns1 + rem * 8;
+        xbase[2][k] = ms_col2 ? nc * ms_ns2 + oc : n * ms_ns2 + rem * 8;
       }
     }
     xoff[k] = off;
@@ -1552,12 +1559,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
           // source select by scalar compares (no dynamically indexed kernel-argument loads inside the K loop)
           const bool g1 = vb >= ms_cb1, g2 = vb >= ms_cb2;
           const h16_t* sp = g2 ? ms_p2 : (g1 ? ms_p1 : ms_p0);
-          const long sns = g2 ? ms_ns2 : (g1 ? ms_ns1 : ms_ns0);
           const int scb = g2 ? ms_cb2 : (g1 ? ms_cb1 : 0);
-          const bool col = g2 ? ms_col2 : (g1 ? ms_col1 : ms_col0);
-          const bool ok = st < NS && xn[k] >= 0 && vb < ms_cbtot;
-          const long o = (long)(col ? xnc[k] : xn[k]) * sns + (col ? xoc[k] : xo[k]) + (long)(vb - scb) * ms_plane;
-          xa = ok ? (unsigned long long)(sp + o) : (unsigned long long)zp;
+          const long xbk = g2 ? xbase[2][k] : (g1 ? xbase[1][k] : xbase[0][k]);
+          const bool ok = st < NS && xbk >= 0 && vb < ms_cbtot;
+          xa = ok ? (unsigned long long)(sp + (long)(vb - scb) * ms_plane + xbk) : (unsigned long long)zp;
         } else {
           const bool ok = st < NS && xoff[k] >= 0 && pr < ah.Cbp;
           xa = ok ? (unsigned long long)(xg + (long)pr * 2 * ah.x_plane_e + xoff[k]) : (unsigned long long)zp;
