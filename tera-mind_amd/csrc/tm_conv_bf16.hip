@@ -1400,6 +1400,16 @@ extern "C" int tm_diag_stamp_count(void) {
 // NWV = waves per workgroup: 8 (one 128 x 512 / 64 x 1024 workgroup per CU) or 4 (two co-resident 128 x 256 / 64 x 512
 // workgroups per CU: the K loops here are 4..64 stages long, and with a single workgroup per CU nothing covers its ring
 // fill, drain and epilogue; with two, one's tail overlaps the other's MFMAs).
+// a / b for 0 <= a < 2^21, 0 < b, rb = 1.0f / b: float multiply + one correction step instead of the ~40-instruction integer
+// division (quarter-rate multiplies); `small` false (wave-uniform): the plain division
+__device__ __forceinline__ int idiv_small(int a, int b, float rb, bool small) {
+  if (!small) return a / b;
+  int q = (int)((float)a * rb);
+  const int r = a - q * b;
+  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
+
 template <int TN, int NWV>
 struct H1Geo {
   static constexpr int NT = NWV * 64;
@@ -1447,6 +1457,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   const h16_t* xg = (const h16_t*)a.x;
   const h16_t* wg = (const h16_t*)a.w;
   const h16_t* zp = (const h16_t*)zero_page;
+  // voxel -> (patch, in-patch index): the tile's first voxel is split by one wave-uniform 64-bit division, every lane's voxel
+  // by a 32-bit one from there (a 64-bit division per piece and per output voxel tile made the prologue 3 k cycles, 7.6 k with
+  // the concat input's index arithmetic on top)
+  const long vg0 = (long)mtile * G::TM;
+  const int VPNi = (int)VPN;
+  const long n0 = vtot <= 0x7fffffffL ? (long)((int)vg0 / VPNi) : vg0 / VPN;
+  const int rem0 = (int)(vg0 - n0 * VPN);
+  const long vleft = vtot - vg0;                       // voxels from the tile's first one to the end of the tensor
+  const bool dsm = vtot <= 0x7fffffffL && a.N < (1 << 21) && VPN + G::TM < (1 << 21);      // idiv_small's range
+  const float rVPN = 1.0f / (float)VPNi;
 
   // piece i = tid + k*NT -> LDS slot WSLOTS + i ([kp][k-half][voxel]); (kp, half) are the same for every lane of an
   // instruction (NT divides TM or equals it), the voxel differs per lane.  Per piece: the voxel's element offset inside
@@ -1465,6 +1485,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   const bool ms_col0 = cx.col0 != 0, ms_col1 = cx.col1 != 0, ms_col2 = cx.col2 != 0;
   const int ms_S = a.S, ms_q1 = cx.p1 - 1, ms_q2 = cx.p2 - 1, ms_pp1 = cx.p1, ms_pp2 = cx.p2;
   const long ms_plane = ah.x_plane_e;
+  const float ms_rSS = 1.0f / (float)(ms_S * ms_S), ms_rS = 1.0f / (float)ms_S;
+  const float ms_rq12 = 1.0f / (float)(ms_q1 * ms_q2), ms_rq2 = 1.0f / (float)ms_q2;
 #pragma unroll
   for (int k = 0; k < G::PX; ++k) {
     const int i = tid + k * NT;
@@ -1472,20 +1494,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
     const int half = (i / G::TM) & 1;
     xkp[k] = i / (2 * G::TM);
     xhalf[k] = half;
-    const long vg = (long)mtile * G::TM + v;
     long off = -1;
     xbase[0][k] = -1; xbase[1][k] = -1; xbase[2][k] = -1;
-    if (vg < vtot) {
-      const long n = vg / VPN;
-      const int rem = (int)(vg - n * VPN);
+    if (v < vleft) {
+      const int r0 = rem0 + v, dn = idiv_small(r0, VPNi, rVPN, dsm);     // the tile's first voxel was split by ONE division
+      const long n = n0 + dn;
+      const int rem = r0 - dn * VPNi;
       off = n * ah.x_nstride_e + (long)half * ah.x_plane_e + (long)rem * 8;
       if (multi) {
         const int S = ms_S;
-        const int z = rem / (S * S), r2 = rem - z * S * S;
-        const int y = r2 / S, x = r2 - y * S;
+        const int z = idiv_small(rem, S * S, ms_rSS, dsm), r2 = rem - z * S * S;
+        const int y = idiv_small(r2, S, ms_rS, dsm), x = r2 - y * S;
         const int q1 = ms_q1, q2 = ms_q2;
-        const int bi = (int)n / (q1 * q2), q = (int)n - bi * q1 * q2;
-        int pi = q / q2, pj = q - pi * q2;
+        const int bi = idiv_small((int)n, q1 * q2, ms_rq12, dsm), q = (int)n - bi * q1 * q2;
+        int pi = idiv_small(q, q2, ms_rq2, dsm), pj = q - pi * q2;
         int ys = y + S / 2, xs = x + S / 2;
         if (ys >= S) { ys -= S; pi += 1; }
         if (xs >= S) { xs -= S; pj += 1; }
@@ -1506,11 +1528,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv1_bf16(ConvArgsH ah, const vo
   for (int mt = 0; mt < 4; ++mt) {
     const int v = (wm * 4 + mt) * 32 + i32;
     xb[mt] = G::WSLOTS + h * G::TM + v;                // consecutive lanes, consecutive slots: conflict free
-    const long vg = (long)mtile * G::TM + v;
-    if (vg < vtot) {
-      const long n = vg / VPN;
-      on[mt] = (int)n;
-      ooff[mt] = (int)((vg - n * VPN) * 8);
+    if (v < vleft) {
+      const int r0 = rem0 + v, dn = idiv_small(r0, VPNi, rVPN, dsm);
+      on[mt] = (int)n0 + dn;
+      ooff[mt] = (r0 - dn * VPNi) * 8;
     } else { on[mt] = 0; ooff[mt] = -1; }
   }
   const int wb = (wn * 64 + i32) * 2 + (h ^ ((i32 >> 3) & 1));
