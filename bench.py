@@ -152,6 +152,7 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
     cfg = PathConfig(gen_type="ddim", compute_dtype=args.sweep_dtype)
     log(f"sweep: packing {args.sweep_dtype} weights")
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
+    model.overlap_streams = args.overlap_streams
     T = 15                                                    # test_brn default: 15-step DDIM (test_brn.py:329-330)
     smp = SpacedDiffusionBeatGans(T, "ddim")
     # share_halo needs gene tiles that agree where they overlap (as tiles cut from one gene map do): the block-seeded provider
@@ -199,7 +200,7 @@ def run_sweep_bench(args, dev, sd, world, rank, steps, warmup):
            "share_halo": share,
            # level 0 of the RNA conditioning (gene attention -> down_z) kept per model call from the first step of the sweep on (the
            # warm-up step here): the timed steps are steps 2 .. T of a sweep, the first one costs ~2.5 % more
-           "cache_level0": bool(args.sweep_cache_level0),
+           "cache_level0": bool(args.sweep_cache_level0), "overlap_streams": args.overlap_streams,
            "first_step_s": round(first_s, 4) if first_s is not None else None,
            "value_full_sweep": (round(400.0 * tiles * T / (first_s + (T - 1) * steady_s), 3) if first_s is not None else None),
            "value_full_sweep_note": f"patch-steps/s of a whole T = {T} sweep = 400 x tiles x T / (measured first step + (T - 1) x measured steady step)",
@@ -281,6 +282,7 @@ def worker(args):
     if not args.sweep:
         log("packing + uploading weights")
         model = BeatGANsUNetModel(cfg, dev).load_state_dict(sd)
+        model.overlap_streams = args.overlap_streams
         log("model ready")
         launch.broadcast_arena(model)      # replaces DDP's construction-time parameter broadcast (test_brn.py:149)
         smp = SpacedDiffusionBeatGans(T_STEPS, gen)
@@ -401,6 +403,9 @@ def main():
     ap.add_argument("--sweep", action="store_true",
                     help="measure ONLY the row-sharded tile sweep (strong scaling; --steps / --warmup are diffusion steps of the ROI)")
     ap.add_argument("--no-sweep", action="store_true", help="default mode: skip the short sweep appended as the `sweep` object")
+    ap.add_argument("--overlap-streams", type=int, default=1,
+                    help="2: the model runs the two halves of a call's images on two HIP streams (bit-identical; faster wall clock, but "
+                         "per-kernel durations -- the roofline fields -- then include the other stream's interference). Default 1")
     ap.add_argument("--no-tile-extra", action="store_true", help="default mode: skip the stacked one-tile 16-bit step appended as `extra`")
     ap.add_argument("--sweep-hnm", type=int, default=8)
     ap.add_argument("--sweep-wnm", type=int, default=8)

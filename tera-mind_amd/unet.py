@@ -62,7 +62,13 @@ class _HipModel(torch.nn.Module):
         with torch.cuda.device(self.device):
             _lib.check(self._L.tm_model_create(C.byref(cfg), C.byref(self._h)), "tm_model_create")
         self._finalized = False
-        self._ws = None
+        self._ws = {}                     # workspace per stream: calls on different streams never share scratch memory
+        self._side = None                 # second stream of overlap_streams = 2
+        # overlap_streams = 2: forward() runs the two halves of a call's images on two HIP streams (images are independent; results
+        # bit-identical).  One stream's last partial round of conv workgroups and its HBM-bound block-input passes / Linears run
+        # beside the other's MFMA-bound convs: one test_brn tile step 51.4 -> 50.3 ms (profiles/r03_two_streams.txt).  Off by
+        # default: per-kernel durations (bench.py's roofline, rocprof summaries) are only meaningful without the overlap.
+        self.overlap_streams = 1
         # lets `next(model.parameters()).device` (reference diffusion/base.py:562) work
         self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.device), requires_grad=False)
 
@@ -110,10 +116,15 @@ class _HipModel(torch.nn.Module):
                 "executed_flops": st.executed_flops, "alg_bytes": st.alg_bytes}
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = _lib.current_stream_ptr()
+        key = int(getattr(key, "value", key) or 0)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws.pop(key, None)
+            ws = None
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
 
     def __del__(self):
         try:
@@ -220,21 +231,42 @@ class BeatGANsUNetModel(_HipModel):
                 raise ValueError(f"rna has shape {tuple(rna_d.shape)}, expected {(ne, gn, gn, zg)}")
         pred = torch.empty((nd, C_, patch_size, patch_size), dtype=torch.float32, device=self.device)
         pred2 = torch.empty_like(x) if want_pred2 else None
-        with torch.cuda.device(self.device):
-            need = self._L.tm_workspace_bytes(self._h, b, p1, p2, int(want_pred2))
+
+        def run(i0, i1):                  # images i0 .. i1 - 1 of the call, on the current stream, into their slices of pred / pred2
+            bb, pe, pd = i1 - i0, p1 * p2, (p1 - 1) * (p2 - 1)
+            xs, ts, ps_ = x[i0 * pe:i1 * pe], t[i0:i1], pred[i0 * pd:i1 * pd]
+            p2s = pred2[i0 * pe:i1 * pe] if want_pred2 else None
+            need = self._L.tm_workspace_bytes(self._h, bb, p1, p2, int(want_pred2))
             ws = self._workspace(need)
-            if isinstance(pyr, RnaLevel0):
-                _lib.check(self._L.tm_unet_forward_level0(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(pyr.buf), pyr.buf.numel(), b, p1,
-                                                          p2, _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+            if isinstance(pyr, RnaLevel0):                                    # patch-major: an image's slice is contiguous
+                per = pyr.buf.numel() // (pyr.b * pe)
+                l0 = pyr.buf[i0 * pe * per:i1 * pe * per]
+                _lib.check(self._L.tm_unet_forward_level0(self._h, _lib.ptr(xs), _lib.ptr(ts), _lib.ptr(l0), l0.numel(), bb, p1,
+                                                          p2, _lib.ptr(ps_), _lib.ptr(p2s), _lib.ptr(ws), ws.numel(),
                                                           _lib.current_stream_ptr()), "tm_unet_forward_level0")
             elif pyr is not None:
-                _lib.check(self._L.tm_unet_forward_rna(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(pyr.buf), pyr.buf.numel(), b, p1, p2,
-                                                       _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+                _lib.check(self._L.tm_unet_forward_rna(self._h, _lib.ptr(xs), _lib.ptr(ts), _lib.ptr(pyr.buf), pyr.buf.numel(), bb, p1, p2,
+                                                       _lib.ptr(ps_), _lib.ptr(p2s), _lib.ptr(ws), ws.numel(),
                                                        _lib.current_stream_ptr()), "tm_unet_forward_rna")
             else:
-                _lib.check(self._L.tm_unet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(rna_d), b, p1, p2,
-                                                   _lib.ptr(pred), _lib.ptr(pred2), _lib.ptr(ws), ws.numel(),
+                rs = rna_d[i0 * pe:i1 * pe]
+                _lib.check(self._L.tm_unet_forward(self._h, _lib.ptr(xs), _lib.ptr(ts), _lib.ptr(rs), bb, p1, p2,
+                                                   _lib.ptr(ps_), _lib.ptr(p2s), _lib.ptr(ws), ws.numel(),
                                                    _lib.current_stream_ptr()), "tm_unet_forward")
+
+        with torch.cuda.device(self.device):
+            # the RnaPyramid buffer is opaque (several tensors per call): only level-0 / dense-gene calls are split
+            if self.overlap_streams >= 2 and b >= 2 and not isinstance(pyr, RnaPyramid):
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                cur, half = torch.cuda.current_stream(self.device), (b + 1) // 2
+                self._side.wait_stream(cur)                                   # inputs were produced on the caller's stream
+                run(0, half)
+                with torch.cuda.stream(self._side):
+                    run(half, b)
+                cur.wait_stream(self._side)                                   # the caller's stream sees both halves complete
+            else:
+                run(0, b)
         return AutoencReturn(pred=pred, pred2=pred2, cond=cond)
 
 

@@ -254,6 +254,34 @@ def test_cached_rna_level0_is_bit_identical(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_overlap_streams_is_bit_identical(dtype):
+    """model.overlap_streams = 2: the two halves of a call's images on two HIP streams (a workspace per stream) return the bits of the
+    one-stream call -- dense genes and cached level 0, odd image count, pred2 too; a call on a caller-chosen side stream works and
+    the stream's own workspace is kept apart from the default stream's."""
+    cfg = PathConfig(compute_dtype=dtype)
+    m = BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    b, P = 3, 2
+    x, t, rna = make_inputs(b, P, seed=17)
+    x, rna, t = x.to(DEV), rna.to(DEV), torch.tensor([7, 950, 333]).to(DEV)
+    shp = torch.zeros(b, 4, 64 * P, 64 * P)
+    l0 = m.precompute_rna_level0(rna, b, imgs=shp, patch_size=64)
+    ref = m(x=x, t=t, rna=rna, imgs=shp, patch_size=64, want_pred2=True)
+    m.overlap_streams = 2
+    for r in (rna, l0):
+        got = m(x=x, t=t, rna=r, imgs=shp, patch_size=64, want_pred2=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got.pred, ref.pred) and torch.equal(got.pred2, ref.pred2)
+    assert len(m._ws) == 2                                  # the caller's stream and the model's side stream
+    m.overlap_streams = 1
+    s = torch.cuda.Stream(device=DEV)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        got = m(x=x, t=t, rna=rna, imgs=shp, patch_size=64)
+    s.synchronize()
+    assert torch.equal(got.pred, ref.pred) and len(m._ws) == 3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_half_resolution_conditioning_is_bit_identical(dtype, tmp_path):
     """The AttnBlock computes SiLU(cond), the 7C adaLN modulation, the cross-cond chunk, k and v once per aligned
     2 x 2 voxel block (cond is a nearest-x2 upsampled RNA level: unet_ours.py:290-295, MBAblocks.py:463-466,472-479,487) and

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--batch_tiles", type=int, default=4)
     ap.add_argument("--batch_rows", type=int, default=1, help="tile rows per shared-halo window")
+    ap.add_argument("--overlap_streams", type=int, default=1, help="2: two halves of a model call's images on two HIP streams")
     ap.add_argument("--z_group", type=int, default=0, help="images (z-chunks) per model call (0: all 25 of a window at once)")
     ap.add_argument("--deadline_s", type=float, default=1100.0)
     a = ap.parse_args()
@@ -37,6 +38,7 @@ def main():
     dev = "cuda:0"
     cfg = PathConfig(gen_type="ddim", compute_dtype=a.dtype)
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
+    model.overlap_streams = a.overlap_streams
     T = 15
     genes = consistent_gene_provider(cfg, dev, max_blocks=(a.batch_rows + 2) * (a.batch_tiles + 2) + 6,
                                      max_tiles=a.batch_rows * (a.batch_tiles + 2))
@@ -84,7 +86,7 @@ def main():
     out = {"what": "one diffusion step of one rank's share of the whole-brain sweep (8-GPU row-block partition), measured on one MI355X",
            "rows": a.rows, "cols": a.cols, "tiles_in_share": a.rows * a.cols, "tiles_measured": done_tiles, "full_step": full,
            "dtype": a.dtype, "state": "fp16 single canvas", "canvas_gb": round(sw.cur.numel() * 2 / 1e9, 1),
-           "window_tiles": [a.batch_rows, a.batch_tiles], "z_group": a.z_group or None, "share_halo": True,
+           "window_tiles": [a.batch_rows, a.batch_tiles], "z_group": a.z_group or None, "overlap_streams": a.overlap_streams, "share_halo": True,
            "seconds": round(el, 1), "s_per_tile_step": round(per_tile, 5), "interior_patch_steps_per_s": round(400 / per_tile, 1),
            "step_s_for_the_share": round(per_tile * a.rows * a.cols, 1),
            "whole_brain_T15_8gpu_hours_from_this": round(per_tile * a.rows * a.cols * 15 / 3600, 2),

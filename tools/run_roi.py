@@ -45,6 +45,7 @@ def worker(args):
     launch.init_distributed("nccl", dev)
     cfg = PathConfig(compute_dtype=args.dtype)
     model = BeatGANsUNetModel(cfg, dev).load_state_dict(hashed_state_dict(cfg, 0))
+    model.overlap_streams = args.overlap_streams
     T = args.tot_epoch
     holder = {}
     if args.deadline_s and world > 1:
@@ -105,7 +106,7 @@ def worker(args):
                           "step_s": [round(v, 2) for v in per_step], "process_age_s": round(time.monotonic() - _T_START, 1),
                           "tile_files_written": d is not None, "dtype": args.dtype, "state": args.state, "tiles": tiles, "T": T,
                           "n_gpus": world, "genes": "on-disk COO .npz via GeneTileDir + tm_gene_tile_dense" if args.gene_dir else "synthetic, device resident",
-                          "init": args.init, "batch_tiles": args.batch_tiles, "share_halo": bool(args.share_halo), "batch_rows": args.batch_rows, "cache_level0": bool(args.cache_level0),
+                          "init": args.init, "batch_tiles": args.batch_tiles, "share_halo": bool(args.share_halo), "batch_rows": args.batch_rows, "cache_level0": bool(args.cache_level0), "overlap_streams": args.overlap_streams,
                           "sweep_s": round(sweep_s, 2), "sweep_min": round(sweep_s / 60, 2), "s_per_tile_step": round(sweep_s * world / (tiles * T), 4),
                           "interior_patch_steps_per_s": round(400 * tiles * T / sweep_s, 1),
                           "first_step_s": round(per_step[0], 2), "last_step_s": round(per_step[-1], 2),
@@ -131,6 +132,7 @@ def main():
                     help="reference = the LCG-seeded CPU mt19937 noise of MBADataset_tst (slow: ~0.1 s per tile)")
     ap.add_argument("--batch_tiles", type=int, default=1)
     ap.add_argument("--batch_rows", type=int, default=1, help="tile rows per model call (with --share_halo 1)")
+    ap.add_argument("--overlap_streams", type=int, default=1, help="2: two halves of a call's images on two HIP streams (bit-identical)")
     ap.add_argument("--cache_level0", type=int, default=0,
                     help="1: keep level 0 of the RNA conditioning of every model call across the steps (ROI scale: 27-37 MB per tile)")
     ap.add_argument("--share_halo", type=int, default=0,
