@@ -689,9 +689,9 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs pa) {
         r[j] += v;
         if (L.norm_w) v = wn[j] * (v * rstd[sub]);
         if (L.mod != MOD_NONE) v = v * (1.0f + sc[j]) + sh[j];
-        // SiLU: exact expf / division where the result stays fp32; hardware exp2 / rcp (1 ulp) where it is rounded to a
-        // 16-bit type anyway (the 16-bit modes: 8 or 11 significant bits survive)
-        if (L.act) v = L.out_h ? silu_h16(v) : silu_f(v);
+        // SiLU on the hardware exp2 / rcp (1 ulp each, ~3e-7 relative on the result) in fp32 too: libm expf + an IEEE division
+        // are ~30 VALU instructions per element of an otherwise HBM-bound pass (configs[1] fp32: 55.22 -> 54.63 ms same box)
+        if (L.act) v = silu_h16(v);
         if (L.drop_mask) v *= L.drop_mask[(long)n * L.drop_ns + (long)gb * oplane + oin + j] * L.drop_scale;
         o[j] += v;
       }
