@@ -55,14 +55,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native 16-b
 
 // SiLU / tanh-GELU on the hardware exp2 / rcp (1 ulp each) for results that are rounded to a 16-bit type right away
 __device__ __forceinline__ float silu_fast(float x) { return silu_h16(x); }
-// 0.5 x (1 + tanh u) = x / (1 + e^{-2u}),  u = sqrt(2/pi) (x + 0.044715 x^3);  -2u log2(e) = x (k0 + k1 x^2): two multiplies,
-// one FMA and one add around the two transcendentals (the epilogue of fc1 is VALU-bound on this: 4C values per voxel)
-__device__ __forceinline__ float gelu_tanh_fast(float x) {
-  constexpr float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-  constexpr float k1 = k0 * 0.044715f;
-  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0));
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
+__device__ __forceinline__ float gelu_tanh_fast(float x) { return gelu_tanh_hw(x); }
 
 struct ConvArgsH {
   ConvArgs c;                 // x / w are reinterpreted: x = bf16 CB8 (elements), w = bf16 packed

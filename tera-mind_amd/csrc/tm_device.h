@@ -35,6 +35,15 @@ struct DevOnce {
 #endif
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// tanh-GELU on the hardware exp2 / rcp: 0.5 x (1 + tanh u) = x / (1 + e^{-2u}),  u = sqrt(2/pi) (x + 0.044715 x^3);
+// -2u log2(e) = x (k0 + k1 x^2): two multiplies, one FMA and one add around the two transcendentals (libm tanhf is ~50
+// instructions; the epilogue of fc1 handles 4C values per voxel).  ~3e-7 relative on the result.
+__device__ __forceinline__ float gelu_tanh_hw(float x) {
+  constexpr float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  constexpr float k1 = k0 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, k1, k0));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 // SiLU for results that are rounded to a 16-bit type right away: v_exp_f32 and v_rcp_f32 (1 ulp each).  NOT `__frcp_rn`, which
 // is an IEEE division on this compiler (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ten VALU instructions per
 // value; the block-input passes and the fused conv epilogue were VALU-bound on it, profiles/r03_silu_rcp.txt)
@@ -153,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[W
         o[3] = acc[ct][mt][4 * g + 3] + bv[3];
         if (a.flags & EPI_GELU) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_f(o[j]);
+          for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_hw(o[j]);
         }
         const long pl = (long)cob * a.y_plane + ooff[mt] + 4 * h;
         if (a.gate) {
