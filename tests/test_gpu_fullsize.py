@@ -162,9 +162,9 @@ def test_forward_does_not_read_uninitialised_workspace(dtype):
         kw = dict(x=x, t=t, rna=rna, imgs=torch.empty((b, 4, 64 * (p1 - 1), 64 * (p2 - 1)), device="meta"), patch_size=64,
                   want_pred2=True)
         m(**kw)                                            # sizes the workspace
-        m._ws.fill_(0xFF)
+        [w.fill_(0xFF) for w in m._ws.values()]
         a = m(**kw)
-        m._ws.zero_()
+        [w.zero_() for w in m._ws.values()]
         c = m(**kw)
         assert torch.isfinite(a.pred).all() and torch.isfinite(a.pred2).all(), dtype
         assert torch.equal(a.pred, c.pred) and torch.equal(a.pred2, c.pred2), dtype

@@ -63,7 +63,7 @@ def main():
 
         out[f"{dtype}.replay1_vs_eager"] = cmp(replay(), eager[0])
         out[f"{dtype}.replay2_vs_eager"] = cmp(replay(), eager[0])
-        m._ws.fill_(0xFF)
+        [w.fill_(0xFF) for w in m._ws.values()]
         out[f"{dtype}.replay_poisoned_ws_vs_eager"] = cmp(replay(), eager[0])
         sx.copy_(xs[1]); st.copy_(ts[1]); sr.copy_(rs[1])
         out[f"{dtype}.replay_new_inputs_vs_eager"] = cmp(replay(), eager[1])
