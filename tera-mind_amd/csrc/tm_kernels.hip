@@ -1227,23 +1227,32 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
   const int z = rem / (S * S); rem -= z * S * S;
   const int y = rem / S, x = rem - y * S;
   const int cob0 = blockIdx.y * 4;                 // 4 cout blocks (32 couts) per thread
-  float acc[32];
+  // accumulators as pairs: one v_pk_fma_f32 per two couts (the weights are wave-uniform SGPR pairs); each accumulator still sees
+  // the same sequence of FMAs, so the result bits do not change
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc2[16];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) acc[j] = a.bias[cob0 * 8 + j];
+  for (int j = 0; j < 16; ++j) acc2[j] = f32x2_t{a.bias[cob0 * 8 + 2 * j], a.bias[cob0 * 8 + 2 * j + 1]};
   for (int ci = 0; ci < a.Cin; ++ci) {
     const float* xp = a.x + (((long)n * a.Cin + ci) * a.Z + z) * S * S;
-#pragma unroll
+    // one tap's 32 wave-uniform weights (SGPRs) at a time: with the nine taps unrolled the 288 weights of a channel did not
+    // fit the scalar register file and were spilled to VGPR lanes (v_writelane / v_readlane: 3 x the FMA count)
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
+#pragma unroll 1
       for (int kx = 0; kx < 3; ++kx) {
         const int yi = y + ky - 1, xi = x + kx - 1;
         const float xv = (yi >= 0 && yi < S && xi >= 0 && xi < S) ? xp[yi * S + xi] : 0.f;
         const float* wp = a.w + ((long)(ky * 3 + kx) * a.Cin + ci) * a.Cop + cob0 * 8;
+        const f32x2_t xv2 = {xv, xv};
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = fmaf(wp[j], xv, acc[j]);
+        for (int j = 0; j < 16; ++j) acc2[j] = __builtin_elementwise_fma(f32x2_t{wp[2 * j], wp[2 * j + 1]}, xv2, acc2[j]);
       }
     }
   }
+  float acc[32];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { acc[2 * j] = acc2[j][0]; acc[2 * j + 1] = acc2[j][1]; }
   if (a.y_h) {
     uint16_t* hp = a.y_h + (long)n * a.yh_nstride + ((long)(z * S + y) * S + x) * 8;
 #pragma unroll
@@ -1289,7 +1298,8 @@ struct HeadArgs {
 };
 // H16: 0 = fp32 CB8 input, 1 = bf16, 2 = fp16 (the 16-bit modes hand the normalised, activated tensor over in 16 bits like
 // every other conv input: half the bytes of the 9-tap gather)
-template <int H16>
+// CO = couts computed (4: the two-stain models -- half the FMAs of the padded 8; 8: anything up to 8)
+template <int H16, int CO>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   const int S = a.S;
   const long vpn = (long)a.Z * S * S;
@@ -1299,9 +1309,10 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   int rem = (int)(vidx - (long)n * vpn);
   const int z = rem / (S * S); rem -= z * S * S;
   const int y = rem / S, x = rem - y * S;
-  float acc[8];
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc2[CO / 2];                                            // pairs of couts: v_pk_fma_f32, same FMA sequence per cout
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int j = 0; j < CO / 2; ++j) acc2[j] = f32x2_t{0.f, 0.f};
   const float* xb = a.x + (long)n * a.x_nstride;                   // H16: the same offsets count 16-bit elements
   const uint16_t* xbh = (const uint16_t*)a.x + (long)n * a.x_nstride;
   // channel block outermost: the 9 taps of one block touch 3 rows of one plane back to back (L1 hits); with the
@@ -1333,23 +1344,33 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
         }
         const float* wp = a.w + ((long)(ky * 3 + kx) * a.Cb + cb) * 64;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < 8; ++c) {
+          const f32x2_t xv2 = {xv[c], xv[c]};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = fmaf(wp[c * 8 + j], xv[c], acc[j]);
+          for (int j = 0; j < CO / 2; ++j)
+            acc2[j] = __builtin_elementwise_fma(f32x2_t{wp[c * 8 + 2 * j], wp[c * 8 + 2 * j + 1]}, xv2, acc2[j]);
+        }
       }
     }
   }
-  for (int j = 0; j < a.Cout; ++j)
-    a.y[(((long)n * a.Cout + j) * a.Z + z) * S * S + (long)y * S + x] = acc[j] + a.bias[j];
+#pragma unroll
+  for (int j = 0; j < CO; ++j)
+    if (j < a.Cout) a.y[(((long)n * a.Cout + j) * a.Z + z) * S * S + (long)y * S + x] = acc2[j / 2][j % 2] + a.bias[j];
 }
 hipError_t launch_head(TV x, float* y, const float* w, const float* bias, int Cout, hipStream_t s, int h16) {
   if (Cout > 8 || h16 < 0 || h16 > 2) return hipErrorInvalidValue;
   HeadArgs a{x.p, x.nstride, x.Cb, y, w, bias, x.N, Cout, x.Z, x.H};
   const long vox = (long)x.N * x.Z * x.H * x.W;
   const dim3 grid((unsigned)((vox + 255) / 256));
-  if (h16 == 0) hipLaunchKernelGGL(head_kernel<0>, grid, dim3(256), 0, s, a);
-  else if (h16 == 1) hipLaunchKernelGGL(head_kernel<1>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(head_kernel<2>, grid, dim3(256), 0, s, a);
+  if (Cout <= 4) {
+    if (h16 == 0) hipLaunchKernelGGL((head_kernel<0, 4>), grid, dim3(256), 0, s, a);
+    else if (h16 == 1) hipLaunchKernelGGL((head_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((head_kernel<2, 4>), grid, dim3(256), 0, s, a);
+  } else {
+    if (h16 == 0) hipLaunchKernelGGL((head_kernel<0, 8>), grid, dim3(256), 0, s, a);
+    else if (h16 == 1) hipLaunchKernelGGL((head_kernel<1, 8>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((head_kernel<2, 8>), grid, dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 

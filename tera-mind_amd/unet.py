@@ -64,8 +64,8 @@ class _HipModel(torch.nn.Module):
         self._finalized = False
         self._ws = {}                     # workspace per stream: calls on different streams never share scratch memory
         self._side = None                 # second stream of overlap_streams = 2
-        # overlap_streams = 2: forward() runs the two halves of a call's images on two HIP streams (images are independent; results
-        # bit-identical).  One stream's last partial round of conv workgroups and its HBM-bound block-input passes / Linears run
+        # overlap_streams = 2: forward() runs the two halves of a call's images on two HIP streams, each on its half of the call's
+        # workspace (images are independent; results bit-identical).  One stream's last partial round of conv workgroups and its HBM-bound block-input passes / Linears run
         # beside the other's MFMA-bound convs: one test_brn tile step 51.4 -> 50.3 ms (profiles/r03_two_streams.txt).  Off by
         # default: per-kernel durations (bench.py's roofline, rocprof summaries) are only meaningful without the overlap.
         self.overlap_streams = 1
@@ -232,12 +232,12 @@ class BeatGANsUNetModel(_HipModel):
         pred = torch.empty((nd, C_, patch_size, patch_size), dtype=torch.float32, device=self.device)
         pred2 = torch.empty_like(x) if want_pred2 else None
 
-        def run(i0, i1):                  # images i0 .. i1 - 1 of the call, on the current stream, into their slices of pred / pred2
+        def run(i0, i1, ws=None):         # images i0 .. i1 - 1 of the call, on the current stream, into their slices of pred / pred2
             bb, pe, pd = i1 - i0, p1 * p2, (p1 - 1) * (p2 - 1)
             xs, ts, ps_ = x[i0 * pe:i1 * pe], t[i0:i1], pred[i0 * pd:i1 * pd]
             p2s = pred2[i0 * pe:i1 * pe] if want_pred2 else None
-            need = self._L.tm_workspace_bytes(self._h, bb, p1, p2, int(want_pred2))
-            ws = self._workspace(need)
+            if ws is None:
+                ws = self._workspace(self._L.tm_workspace_bytes(self._h, bb, p1, p2, int(want_pred2)))
             if isinstance(pyr, RnaLevel0):                                    # patch-major: an image's slice is contiguous
                 per = pyr.buf.numel() // (pyr.b * pe)
                 l0 = pyr.buf[i0 * pe * per:i1 * pe * per]
@@ -260,10 +260,16 @@ class BeatGANsUNetModel(_HipModel):
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.device)
                 cur, half = torch.cuda.current_stream(self.device), (b + 1) // 2
+                # ONE allocation (the caller's stream's workspace) cut in two: the side stream touches its part only between the
+                # two wait_stream calls, and the memory of a call does not grow with the number of streams
+                n0 = self._L.tm_workspace_bytes(self._h, half, p1, p2, int(want_pred2))
+                n1 = self._L.tm_workspace_bytes(self._h, b - half, p1, p2, int(want_pred2))
+                n0 = (n0 + 4095) // 4096 * 4096
+                ws = self._workspace(n0 + n1)
                 self._side.wait_stream(cur)                                   # inputs were produced on the caller's stream
-                run(0, half)
+                run(0, half, ws[:n0])
                 with torch.cuda.stream(self._side):
-                    run(half, b)
+                    run(half, b, ws[n0:n0 + n1])
                 cur.wait_stream(self._side)                                   # the caller's stream sees both halves complete
             else:
                 run(0, b)

@@ -255,7 +255,7 @@ def test_cached_rna_level0_is_bit_identical(dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_overlap_streams_is_bit_identical(dtype):
-    """model.overlap_streams = 2: the two halves of a call's images on two HIP streams (a workspace per stream) return the bits of the
+    """model.overlap_streams = 2: the two halves of a call's images on two HIP streams (the call's workspace cut in two) return the bits of the
     one-stream call -- dense genes and cached level 0, odd image count, pred2 too; a call on a caller-chosen side stream works and
     the stream's own workspace is kept apart from the default stream's."""
     cfg = PathConfig(compute_dtype=dtype)
@@ -271,14 +271,14 @@ def test_overlap_streams_is_bit_identical(dtype):
         got = m(x=x, t=t, rna=r, imgs=shp, patch_size=64, want_pred2=True)
         torch.cuda.synchronize()
         assert torch.equal(got.pred, ref.pred) and torch.equal(got.pred2, ref.pred2)
-    assert len(m._ws) == 2                                  # the caller's stream and the model's side stream
+    assert len(m._ws) == 1                                  # both halves live in the caller's stream's workspace
     m.overlap_streams = 1
     s = torch.cuda.Stream(device=DEV)
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         got = m(x=x, t=t, rna=rna, imgs=shp, patch_size=64)
     s.synchronize()
-    assert torch.equal(got.pred, ref.pred) and len(m._ws) == 3
+    assert torch.equal(got.pred, ref.pred) and len(m._ws) == 2
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
