@@ -43,6 +43,39 @@ def test_unet_vs_reference_outputs(b, P, seed):
         assert torch.allclose(out.pred2.cpu(), ref2, atol=2e-4, rtol=0), util.report("pred2 vs reference", out.pred2, ref2)
 
 
+# rel-L2 bounds of the 16-bit HIP modes against the REFERENCE ITSELF run under torch.autocast('cpu', <dtype>)
+# (oracle/make_autocast_golden.py).  Both sides round conv / Linear / attention operands and results to the 16-bit type and
+# accumulate in fp32; what differs is accumulation order, the fp32 islands (the HIP path keeps the gene attention and the
+# normalisation statistics in fp32) and CPU-vs-CUDA autocast policy at the edges -- so this is a tolerance, not bit parity.
+# Measured: bf16 7.5e-3 / 8.0e-3, f16 9.1e-4 / 9.8e-4 (the reference's own autocast run sits 6.8-7.3e-3 / 8.2-8.8e-4 from its fp32 run,
+# the HIP 16-bit modes 5.0-5.4e-3 / 6.4-6.8e-4 from it: the two 16-bit runs differ by about what either differs from fp32).
+AUTOCAST_TOL = {"bf16": 1.0e-2, "f16": 1.3e-3}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("b,P,seed", [(1, 1, 0), (1, 2, 3)])
+def test_unet_16bit_modes_vs_reference_under_cpu_autocast(dtype, b, P, seed):
+    gold = np.load(os.path.join(G, "unet_autocast_ref.npz"))
+    full = np.load(os.path.join(G, "unet_full.npz"))
+    p = P + 1
+    ne = b * p * p
+    x = synth.normal("x", (ne, 4, 64, 64), seed)
+    rna = synth.gene_counts("rna", (ne, 4, 4, 2000), seed)
+    t = torch.tensor([(137 * (i + 1) + 61 * seed) % 1000 for i in range(b)], dtype=torch.long)
+    cfg = PathConfig(compute_dtype=dtype)
+    m = BeatGANsUNetModel(cfg, DEV).load_state_dict(util.state_dict(cfg))
+    out = m(x=x.to(DEV), t=t.to(DEV), rna=rna.to(DEV), imgs=torch.zeros(b, 4, 64 * P, 64 * P), patch_size=64, want_pred2=(P == 1))
+    tag = f"b{b}_P{P}_s{seed}"
+    rel = lambda a, r: ((a - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+    ref16, ref32 = torch.from_numpy(gold[f"{dtype}/{tag}/pred"]), torch.from_numpy(full[f"{tag}/pred"])
+    e16, e32 = rel(out.pred.cpu(), ref16), rel(out.pred.cpu(), ref32)
+    print(f"HIP {dtype} {tag}: vs reference under CPU autocast {e16:.3e}, vs reference fp32 {e32:.3e}; "
+          f"reference autocast vs reference fp32 {float(gold[f'{dtype}/{tag}/rel_l2_vs_fp32']):.3e}")
+    assert e16 < AUTOCAST_TOL[dtype], (dtype, tag, e16)
+    if P == 1:
+        assert rel(out.pred2.cpu(), torch.from_numpy(gold[f"{dtype}/{tag}/pred2"])) < AUTOCAST_TOL[dtype]
+
+
 def test_sample_mode_A_trajectories_vs_reference():
     """sampler.sample(...) with the reference signature, mode A (gen_sample call shape), fixed noise."""
     gold = np.load(os.path.join(G, "sampler_traj.npz"))
