@@ -65,6 +65,20 @@ def test_unet_forward_vs_reference_fixture(b, P, seed):
         assert torch.allclose(pred2, torch.from_numpy(gold[f"{tag}/pred2"]), atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("dtype,lo,hi", [("bf16", 4e-3, 1e-2), ("f16", 5e-4, 1.3e-3)])
+def test_autocast_reference_fixture_is_consistent(dtype, lo, hi):
+    """tests/golden/unet_autocast_ref.npz (the reference under torch.autocast('cpu', <dtype>), oracle/make_autocast_golden.py)
+    belongs to the same inputs as unet_full.npz: its distance to the fp32 fixture is the stored one and is the size a 16-bit
+    evaluation of this network has (what the GPU test compares the HIP 16-bit modes with)."""
+    gold, full = np.load(os.path.join(G, "unet_autocast_ref.npz")), np.load(os.path.join(G, "unet_full.npz"))
+    for tag in ("b1_P1_s0", "b1_P2_s3"):
+        a, r = torch.from_numpy(gold[f"{dtype}/{tag}/pred"]), torch.from_numpy(full[f"{tag}/pred"])
+        assert a.shape == r.shape and torch.isfinite(a).all()
+        rel = ((a - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+        assert abs(rel - float(gold[f"{dtype}/{tag}/rel_l2_vs_fp32"])) < 1e-9
+        assert lo < rel < hi, (dtype, tag, rel)
+
+
 def test_sampler_trajectories_vs_reference_fixture():
     gold = np.load(os.path.join(G, "sampler_traj.npz"))
     cfg = PathConfig()
