@@ -1692,6 +1692,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
     const h16_t* p = isq ? qb + tokoff[t] : kb + tokoff_kv[t];
     const long pp = isq ? a.plane : kv_plane;
     float ss = 0.f;
+#pragma unroll 8                                              // eight independent 16-byte loads in flight (same summation order)
     for (int cb = 0; cb < C / 8; ++cb) {
       const bf16x8 v8 = *(const bf16x8*)(p + (long)cb * pp);
 #pragma unroll
@@ -1714,6 +1715,44 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
   const h16_t* kp[G::NW];
 #pragma unroll
   for (int ct = 0; ct < G::NW; ++ct) kp[ct] = kb + tokoff_kv[wbase + ct * 32 + i32] + (long)h * kv_plane;
+  // The operands come straight from global memory (each lane its own token's 16-byte entries): with one channel pair
+  // prefetched ahead, every one of the C / 16 steps waited for a load issued four MFMAs earlier -- the loop was a chain of
+  // memory round trips.  PD pairs are in flight now (C / 16 is a multiple of 4 for every width of the model family; otherwise
+  // the one-ahead loop below).
+  constexpr int PD = 4;
+  if (npair % PD == 0) {
+    bf16x8 qs[PD], ks[PD][G::NW];
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      qs[u] = *(const bf16x8*)(qp + (long)u * 2 * a.plane);
+#pragma unroll
+      for (int ct = 0; ct < G::NW; ++ct) ks[u][ct] = *(const bf16x8*)(kp[ct] + (long)u * 2 * kv_plane);
+    }
+    for (int kp0 = 0; kp0 < npair; kp0 += PD) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        const int kp2 = kp0 + u;
+        bf16x8 qf;
+        const bf16x8 qc = qs[u];
+        bf16x8 kf[G::NW];
+#pragma unroll
+        for (int ct = 0; ct < G::NW; ++ct) kf[ct] = ks[u][ct];
+        if (kp2 + PD < npair) {
+          const long po = (long)(kp2 + PD) * 2 * a.plane, pk = (long)(kp2 + PD) * 2 * kv_plane;
+          qs[u] = *(const bf16x8*)(qp + po);
+#pragma unroll
+          for (int ct = 0; ct < G::NW; ++ct) ks[u][ct] = *(const bf16x8*)(kp[ct] + pk);
+        }
+        {
+          const f32x4 wa = *(const f32x4*)(w2 + kp2 * 16 + 8 * h), wb = *(const f32x4*)(w2 + kp2 * 16 + 8 * h + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { qf[j] = (h16_t)((float)qc[j] * wa[j]); qf[4 + j] = (h16_t)((float)qc[4 + j] * wb[j]); }
+        }
+#pragma unroll
+        for (int ct = 0; ct < G::NW; ++ct) acc[ct] = TM_MFMA16(kf[ct], qf, acc[ct]);
+      }
+    }
+  } else {
   bf16x8 qn = *(const bf16x8*)qp, kn[G::NW];
 #pragma unroll
   for (int ct = 0; ct < G::NW; ++ct) kn[ct] = *(const bf16x8*)kp[ct];
@@ -1735,6 +1774,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bf16(WinArgsH a) {
     }
 #pragma unroll
     for (int ct = 0; ct < G::NW; ++ct) acc[ct] = TM_MFMA16(kf[ct], qf, acc[ct]);
+  }
   }
   // ---- scale + softmax over the keys of this lane's query (registers, then lane ^ 32) ----
   {
