@@ -118,12 +118,13 @@ class _HipModel(torch.nn.Module):
     def _workspace(self, nbytes: int) -> torch.Tensor:
         key = _lib.current_stream_ptr()
         key = int(getattr(key, "value", key) or 0)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < nbytes:
-            self._ws.pop(key, None)
             ws = None
+            while len(self._ws) >= 4:     # callers that churn through streams: keep the four most recently used workspaces
+                self._ws.pop(next(iter(self._ws)))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws[key] = ws
+        self._ws[key] = ws                # (re-)inserted last: dict order = least recently used first
         return ws
 
     def __del__(self):
