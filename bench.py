@@ -118,7 +118,9 @@ def roofline_block(prof, dtype, dt_total, value_per_gpu, P, tile, sweep=False):
             rec = json.load(open(pmc_json))
             if rec.get("src_sha") == kernel_source_sha():
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_src = f"{os.path.relpath(pmc_json, ROOT)} @ {rec.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
+                traffic_src = (f"{os.path.relpath(pmc_json, ROOT)} @ {rec.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " +
+                               ("the ONE-TILE step: per launch of one tile's patches -- a launch of this sweep covers a whole window of tiles, "
+                                "scale by executed_gflop_per_launch / 851.3)" if sweep else "this workload)"))
             else:
                 traffic_src = f"{os.path.relpath(pmc_json, ROOT)} is stale (kernel sources changed since it was measured): not reported"
         except Exception:
