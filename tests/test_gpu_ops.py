@@ -186,6 +186,30 @@ def test_conv1_16bit_stream_epilogue(N, Cin, Cout, Z, S, waves, dtype):
     assert torch.equal(got.cpu(), ref), util.report("conv1 stream " + dtype, got, ref)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,Z,S", [(2, 229, 1792, 2, 8), (3, 13, 40, 2, 8), (1, 96, 64, 2, 64), (5, 256, 256, 2, 16)])
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_conv1_16bit_stream_epilogue_plain_and_gelu(N, Cin, Cout, Z, S, waves, dtype):
+    """The stream epilogue kinds without side inputs (conv1_epilogue_stream<1> / <2>: q, k / v, adaLN and fc1 of the AttnBlock):
+    16-bit output of the plain Linear bit-exact on integers (ragged cout blocks, ragged voxel tiles); with tanh-GELU (hardware
+    exp2 / rcp, then rounded to the 16-bit type) to one 16-bit ulp of torch's tanh-GELU of the exact integer pre-activation."""
+    td = util.H16[dtype][1]
+    x = util.rand_int((N, Cin, Z, S, S), -3, 3, 61)
+    w = util.rand_int((Cout, Cin, 1, 1, 1), -2, 2, 62)
+    b = util.rand_int((Cout,), -4, 4, 63)
+    pre = F.conv3d(x, w, b)
+    got, _ = util.conv1_bf16(x.to(DEV), w, b, False, dtype, waves, out16=True)
+    assert torch.equal(got.cpu(), pre.to(td).float()), util.report("conv1 stream plain " + dtype, got, pre)
+    # GELU on small pre-activations (|v| up to a few units: where the curve bends)
+    ws = w * 0.0
+    ws[:, :1] = w[:, :1].sign()                                # one input channel: pre-activation = +-x0 + b in [-7, 7]
+    pre = F.conv3d(x, ws, b)
+    ref = F.gelu(pre, approximate="tanh")
+    got, _ = util.conv1_bf16(x.to(DEV), ws, b, True, dtype, waves, out16=True)
+    ulp = (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) * ref.abs().clamp_min(2.0 ** -14)
+    assert ((got.cpu() - ref).abs() <= 1.01 * ulp + 1e-7).all(), util.report("conv1 stream gelu " + dtype, got, ref)
+
+
 @pytest.mark.parametrize("b,p1,p2,cins,flags,Cout,S", [
     (2, 3, 3, (64, 32), (0, 0), 64, 16),              # encoder block: cat(h, rna), plain
     (1, 2, 4, (128, 64, 32), (1, 1, 1), 128, 8),      # first decoder block of a level: every source re-tiled
