@@ -255,7 +255,9 @@ PREP_CASES = [
     (3, 2, 2, (256,), (0,), 8, False, 1, True),                 # out_layers of a Cout > 128 block: per-image scale / shift
     (2, 2, 2, (128,), (0,), 16, False, 2, True),                # AttnBlock modulate: per-voxel scale / shift, no SiLU
     (2, 2, 3, (229,), (1,), 8, False, 0, False),                # SiLU(cond) of the collage decoder: no norm
-    (1, 2, 2, (512, 512, 229), (0, 1, 1), 8, False, 0, True)]   # 157 channel blocks (the widest concat of the model)
+    (1, 2, 2, (512, 512, 229), (0, 1, 1), 8, False, 0, True),   # 157 channel blocks (the widest concat of the model)
+    (3, 2, 2, (16,), (0,), 8, False, 0, True),                  # 2 channel blocks: two of the four waves own none (clamped loads)
+    (2, 2, 2, (8, 8, 8), (0, 1, 0), 16, False, 2, True)]        # 3 blocks from three sources, per-voxel modulation
 
 
 @pytest.mark.parametrize("b,p1,p2,cins,flags,S,up2,mod,norm", PREP_CASES)
