@@ -248,10 +248,24 @@ def tile_extra(model, cfg, dev, dtype, steps=3, warmup=1):
     model.profile(False)
     assert torch.isfinite(state).all(), "non-finite state"
     value = b * P * P * steps / dt
+    # the same steps with the two halves of the z-chunks on two HIP streams (model.overlap_streams = 2: bit-identical results;
+    # wall clock only -- per-kernel durations overlap, so the roofline above stays the one-stream figure)
+    two = None
+    if getattr(model, "overlap_streams", 1) == 1:
+        model.overlap_streams = 2
+        st2 = one_step(0, state)                                   # sizes the second half's workspace
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            st2 = one_step(k, st2)
+        torch.cuda.synchronize()
+        two = round(1e3 * (time.perf_counter() - t0) / steps, 3)
+        model.overlap_streams = 1
     return {"workload": "one test_brn tile per step: 25 z-chunks x (5x5 padded -> 4x4 interior) patches (P=4, 625 padded + 400 collage "
                         "patches), DDIM T=50 schedule, mode B arithmetic, " + dtype,
             "dtype": dtype, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
             "value": round(value, 3), "unit": "interior patch-steps/s",
+            "ms_per_step_overlap_streams_2": two,
             "roofline": roofline_block(prof, dtype, dt, value, P, True)}
 
 
